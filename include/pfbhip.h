@@ -1,0 +1,236 @@
+/*
+ * pfbhip.h -- C-ABI of libpfbhip.so, the MI355X (gfx950) measurement operator
+ * for pfb-imaging.
+ *
+ * Every entry point replaces one of the third-party native calls the reference
+ * makes on its hot path (the reference is 100 % Python; its FFI for this path
+ * is the ducc0 / numba call boundary).  Citations are file:line under
+ * /root/reference.  All functions return 0 on success and a non-zero status
+ * on failure; pfbhip_last_error() then returns a thread-local message.  No
+ * C++ exception crosses this boundary.  Pointers named *_host are caller-owned
+ * host memory (numpy arrays, possibly read-only); pointers named *_dev are
+ * device memory obtained from pfbhip_malloc.  Complex arrays are interleaved
+ * (re, im) doubles.  All arrays are C-contiguous.
+ *
+ * Threading: a handle is single-caller (like the reference's operators, which
+ * share scratch: src/pfb_imaging/operators/hessian.py:481-485); different
+ * handles may be used from different host threads.  Each handle owns a HIP
+ * stream; calls are synchronous with respect to the host unless stated.
+ */
+#ifndef PFBHIP_H
+#define PFBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFBHIP_OK 0
+#define PFBHIP_ERR_INVALID 1  /* bad argument / shape (-> ValueError)   */
+#define PFBHIP_ERR_RUNTIME 2  /* HIP / rocFFT / RCCL failure (-> RuntimeError) */
+
+/* ---- runtime ------------------------------------------------------- */
+const char *pfbhip_last_error(void);
+int pfbhip_device_count(int *count);
+int pfbhip_set_device(int device);
+int pfbhip_get_device(int *device);
+int pfbhip_device_name(char *buf, size_t buflen);
+int pfbhip_mem_info(size_t *free_bytes, size_t *total_bytes);
+/* replaces ducc0.misc.resize_thread_pool / thread_pool_size (src/pfb_imaging/operators/band_worker.py:50-52):
+ * the "pool" is the GPU; kept so callers need no change. */
+int pfbhip_resize_thread_pool(int nthreads);
+int pfbhip_thread_pool_size(void);
+/* replaces ducc0.fft.good_size (src/pfb_imaging/utils/misc.py:921-951):
+ * smallest 2-3-5-7-11-smooth (real=0) or 2-3-5-smooth (real=1) integer >= n. */
+int64_t pfbhip_good_size(int64_t n, int real);
+
+/* ---- device memory (for device-resident callers: on-device CG, bench) ---- */
+int pfbhip_malloc(void **ptr_dev, size_t bytes);
+int pfbhip_free(void *ptr_dev);
+int pfbhip_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int pfbhip_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int pfbhip_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
+int pfbhip_memset(void *dst_dev, int value, size_t bytes);
+int pfbhip_synchronize(void);
+
+/* ---- w-stacking gridder / degridder --------------------------------- */
+/*
+ * Replaces ducc0.wgridder.experimental.vis2dirty / dirty2vis as called at
+ *   src/pfb_imaging/operators/hessian.py:50-89      (hessian_slice)
+ *   src/pfb_imaging/operators/gridder.py:78,128,590-613,633-656,852-910,972-1016,1067-1117
+ * A handle binds what is constant over a run -- geometry, uvw, freq, mask --
+ * (the reference pins exactly these per band: operators/band_worker.py:61-106)
+ * and holds the tile-sorted visibility index, kernel choice, correction image,
+ * rocFFT plans and device scratch.
+ */
+typedef struct pfbhip_gridder pfbhip_gridder;
+
+typedef struct pfbhip_gridder_params {
+    int64_t nrow, nchan;
+    int64_t nx, ny;               /* npix_x, npix_y                          */
+    double pixsize_x, pixsize_y;  /* radians                                 */
+    double center_x, center_y;    /* as ducc0: x0 = -l0, y0 = -m0 on the pfb path (gridder.py:23-34) */
+    double epsilon;
+    double sigma_min, sigma_max;  /* oversampling bounds (gridder.py:609-610) */
+    int32_t flip_u, flip_v, flip_w;
+    int32_t do_wgridding;
+    int32_t divide_by_n;
+    int32_t verbosity;
+    /* 0 / 0.0 = automatic.  Tests pin the kernel row with these. */
+    int32_t force_W;
+    double force_sigma;
+} pfbhip_gridder_params;
+
+typedef struct pfbhip_gridder_info {
+    int64_t nu, nv;        /* oversampled uv-grid                             */
+    int64_t nplanes;       /* w-planes                                        */
+    int64_t nactive;       /* unmasked visibilities                           */
+    int64_t ntiles, nwork; /* uv tiles, (tile, chunk) work items              */
+    int32_t W, tile;       /* kernel support, tile edge (cells)               */
+    double beta, sigma;    /* ES kernel exp(beta (sqrt(1-x^2) - 1)), design oversampling */
+    double wmin, dw;       /* plane p sits at w = wmin + p dw (wavelengths)   */
+    double nshift, lshift, mshift;
+    double kernel_eps;     /* tabulated 1-D L2 error of the chosen row        */
+    size_t device_bytes;   /* device memory held by the handle                */
+} pfbhip_gridder_info;
+
+int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw_host /* (nrow,3) */,
+                          const double *freq_host /* (nchan) */, const uint8_t *mask_host /* (nrow,nchan) or NULL */,
+                          pfbhip_gridder **out);
+int pfbhip_gridder_destroy(pfbhip_gridder *g);
+int pfbhip_gridder_get_info(const pfbhip_gridder *g, pfbhip_gridder_info *info);
+
+/* The bit-exact uv-cell / tile / plane map, for parity tests: per visibility
+ * (row-major (nrow,nchan)) first-tap indices iu0, iv0, first plane p0, the
+ * Hermitian-fold flag, and `order`, the nactive visibility indices in tile-sorted
+ * order.  Any output pointer may be NULL. */
+int pfbhip_gridder_get_binmap(pfbhip_gridder *g, int32_t *iu0_host, int32_t *iv0_host, int32_t *p0_host,
+                              uint8_t *flip_host, int64_t *order_host);
+
+/* vis2dirty: dirty (nx,ny) = R^H (wgt * mask * vis).  wgt_host may be NULL (ones). */
+int pfbhip_gridder_vis2dirty(pfbhip_gridder *g, const double *vis_host /* (nrow,nchan,2) */,
+                             const double *wgt_host /* (nrow,nchan) or NULL */, double *dirty_host /* (nx,ny) */);
+/* dirty2vis: vis (nrow,nchan) = wgt * mask * R dirty. */
+int pfbhip_gridder_dirty2vis(pfbhip_gridder *g, const double *dirty_host, const double *wgt_host,
+                             double *vis_host /* (nrow,nchan,2) */);
+/* One pre-FFT w-plane of the uv-grid (nu,nv,2), for intermediate parity tests. */
+int pfbhip_gridder_grid_plane(pfbhip_gridder *g, const double *vis_host, const double *wgt_host, int64_t plane,
+                              double *grid_host);
+
+/*
+ * Fused exact Hessian  out = beam * R^H W R (beam * x) / wsum + eta * x
+ * (src/pfb_imaging/operators/hessian.py:15-100).  Weights are bound once with
+ * set_weights (they are constant across CG iterations, opt/pcg.py:519-538);
+ * model visibilities never leave the device.  beam may be NULL; wsum <= 0
+ * means "do not normalise"; eta == 0 skips the Tikhonov term.
+ */
+int pfbhip_gridder_set_weights(pfbhip_gridder *g, const double *wgt_host /* (nrow,nchan) or NULL */);
+int pfbhip_gridder_hessian(pfbhip_gridder *g, const double *x_host, const double *beam_host, double eta, double wsum,
+                           double *out_host);
+int pfbhip_gridder_hessian_dev(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta,
+                               double wsum, double *out_dev);
+/* Device-resident single directions (bench / on-device solvers).  vis_sorted_dev
+ * holds nactive complex values in the handle's tile-sorted order. */
+int pfbhip_gridder_degrid_dev(pfbhip_gridder *g, const double *dirty_dev, double *vis_sorted_dev);
+int pfbhip_gridder_grid_dev(pfbhip_gridder *g, const double *vis_sorted_dev, double *dirty_dev);
+
+/* Per-stage device timing (HIP events on the handle's stream).  Stages:
+ * 0 grid (scatter) 1 degrid (gather) 2 fft 3 pad+screen 4 crop+screen 5 other.
+ * ms[s] = accumulated milliseconds, calls[s] = launches, since the last reset. */
+#define PFBHIP_NSTAGES 6
+int pfbhip_gridder_profile(pfbhip_gridder *g, int enable);
+int pfbhip_gridder_profile_get(pfbhip_gridder *g, double *ms /* [PFBHIP_NSTAGES] */, int64_t *calls, int reset);
+
+/* ---- FFT (replaces ducc0.fft.r2c / c2r) ---------------------------- */
+/* r2c(forward=True, inorm=0) and c2r(forward=False, inorm=2, lastsize) over the last two axes of a
+ * (nbatch, n0, n1) real / (nbatch, n0, n1/2+1) complex array
+ * (src/pfb_imaging/operators/psf.py:20-32, operators/fft.py:10,39, operators/gridder.py:659,912). */
+int pfbhip_r2c_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1, double *out_host);
+int pfbhip_c2r_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1 /* lastsize */, double *out_host);
+
+/* ---- PSF-convolution operator family -------------------------------- */
+/*
+ * One plan serves psf_convolve_slice/cube/fscube (operators/psf.py:8-96),
+ * hessian_psf_slice / hess_direct_slice (operators/hessian.py:103-248),
+ * HessPSF.dot (:313-349) and HessianTree.dot (:487-518):
+ *     out[b] = post[b] * crop( irfft2( rfft2( pad(pre[b] * x[b]) ) * f(psfhat[b]) ) ) * scale + eta[b] * x[b]
+ * with real or complex psfhat resident on the device.
+ */
+typedef struct pfbhip_psfconv pfbhip_psfconv;
+int pfbhip_psfconv_create(int64_t nx, int64_t ny, int64_t nx_psf, int64_t ny_psf, pfbhip_psfconv **out);
+int pfbhip_psfconv_destroy(pfbhip_psfconv *p);
+/* Bind slot `slot` (0 <= slot < nslots, grown on demand) to a Fourier-domain PSF:
+ * is_complex = 0: (nx_psf, ny_psf/2+1) doubles; 1: interleaved complex. */
+int pfbhip_psfconv_set_psfhat(pfbhip_psfconv *p, int64_t slot, const double *psfhat_host, int is_complex);
+/* Bind slot `slot` to an image-plane multiplier (beam / taper), (nx,ny); NULL unbinds. */
+int pfbhip_psfconv_set_beam(pfbhip_psfconv *p, int64_t slot, const double *beam_host);
+/*
+ * mode 0: multiply by psfhat[psf_slot]
+ * mode 1: multiply by (psfhat + shift)          (hess_direct, forward)
+ * mode 2: divide   by (psfhat + shift)          (hess_direct, backward)
+ * beam_slot < 0: no image-plane multiplier.  accumulate != 0: out += result.
+ */
+int pfbhip_psfconv_apply(pfbhip_psfconv *p, const double *x_host, int64_t psf_slot, int64_t beam_slot, int mode,
+                         double shift, double scale, double eta, int accumulate, double *out_host);
+int pfbhip_psfconv_apply_dev(pfbhip_psfconv *p, const double *x_dev, int64_t psf_slot, int64_t beam_slot, int mode,
+                             double shift, double scale, double eta, int accumulate, double *out_dev);
+
+/* ---- on-device conjugate gradients ------------------------------------- */
+/*
+ * Whole-solve entry points: every CG vector stays in HBM, one host call per solve
+ * (replaces the per-iteration host loop of pcg_numba, src/pfb_imaging/opt/pcg.py:88-199,
+ * as used by HessTreeRay.cg -> band_worker.py:124-140 and pcg_dds, opt/pcg.py:519-540).
+ * Same stopping rule: eps = ||x - xp|| / ||x|| <= tol and k >= minit, or k == maxit, or 5 stalls.
+ * x_host holds x0 on entry when has_x0 != 0 (else zeros are used) and the solution on exit.
+ */
+typedef struct pfbhip_cg_info {
+    int32_t iters;
+    int32_t status; /* 0 converged, 1 maxit, 2 stalled, 3 zero initial residual */
+    double eps;     /* last ||x - xp|| / ||x|| */
+    double phi;     /* (r.r) / (r0.r0) */
+} pfbhip_cg_info;
+/* A = (scale) * sum_k beam[beam_slots[k]] * PSF[psf_slots[k]] (*) (beam * .) + eta * I   (HessianTree / HessPSF band) */
+int pfbhip_psfconv_cg(pfbhip_psfconv *p, int64_t nparts, const int64_t *psf_slots, const int64_t *beam_slots,
+                      double scale, double eta, const double *rhs_host, double *x_host, int has_x0, double tol,
+                      int maxit, int minit, pfbhip_cg_info *info);
+/* A = beam * R^H W R (beam * .) / wsum + eta * I   (exact Hessian, weights bound by set_weights) */
+int pfbhip_gridder_cg(pfbhip_gridder *g, const double *beam_host, double eta, double wsum, const double *rhs_host,
+                      double *x_host, int has_x0, double tol, int maxit, int minit, pfbhip_cg_info *info);
+
+/* ---- uv-cell counts / Briggs weights (utils/weighting.py:81-208) ------ */
+/* cell index (u_idx*ny+v_idx, -1 if masked / out of bounds): the bit-exact index map. */
+int pfbhip_uvcell_index(const double *uvw_host, const double *freq_host, const uint8_t *mask_host, int64_t nrow,
+                        int64_t nchan, int64_t nx, int64_t ny, double cell_x, double cell_y, double usign,
+                        double vsign, int64_t *cell_host);
+/* _compute_counts: counts (ncorr,nx,ny) += wgt (ncorr,nrow,nchan) scattered by the index map. */
+int pfbhip_compute_counts(const double *uvw_host, const double *freq_host, const uint8_t *mask_host,
+                          const double *wgt_host, int64_t ncorr, int64_t nrow, int64_t nchan, int64_t nx, int64_t ny,
+                          double cell_x, double cell_y, double usign, double vsign, double *counts_host);
+/* gather-divide half of counts_to_weights: wgt /= counts[cell] where counts > 0. */
+int pfbhip_counts_divide(const double *uvw_host, const double *freq_host, const uint8_t *mask_host,
+                         const double *counts_host, int64_t ncorr, int64_t nrow, int64_t nchan, int64_t nx,
+                         int64_t ny, double cell_x, double cell_y, double usign, double vsign, double *wgt_host);
+
+/* ---- band reduce over xGMI (RCCL) ------------------------------------ */
+/*
+ * Replaces the driver-side band sums of the reference
+ * (src/pfb_imaging/core/grid.py:430-446, core/deconv.py:320-321): one process
+ * per GPU, sum(dirty/residual) to root.  The 128-byte unique id is produced on
+ * rank 0 and carried to the other ranks by the caller's launcher (torchrun /
+ * any store).
+ */
+typedef struct pfbhip_comm pfbhip_comm;
+#define PFBHIP_UNIQUE_ID_BYTES 128
+int pfbhip_comm_unique_id(uint8_t *id /* [PFBHIP_UNIQUE_ID_BYTES] */);
+int pfbhip_comm_create(const uint8_t *id, int nranks, int rank, pfbhip_comm **out);
+int pfbhip_comm_destroy(pfbhip_comm *c);
+int pfbhip_comm_reduce_sum(pfbhip_comm *c, const double *send_dev, double *recv_dev, int64_t count, int root);
+int pfbhip_comm_allreduce_sum(pfbhip_comm *c, const double *send_dev, double *recv_dev, int64_t count);
+int pfbhip_comm_barrier(pfbhip_comm *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFBHIP_H */

@@ -1,0 +1,171 @@
+"""ctypes binding of libpfbhip.so (C-ABI: include/pfbhip.h).
+
+The library is built in-tree by ``pfb-imaging_amd/csrc/Makefile`` (hipcc, gfx950).  There is
+no fallback: if it is missing, importing any operator raises ImportError telling how to build.
+"""
+
+import ctypes as ct
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpfbhip.so")
+
+i32 = ct.c_int32
+i64 = ct.c_int64
+f64 = ct.c_double
+cint = ct.c_int
+vp = ct.c_void_p
+NSTAGES = 6
+STAGE_NAMES = ("grid", "degrid", "fft", "pad_screen", "crop_screen", "other")
+UNIQUE_ID_BYTES = 128
+
+
+class GridderParams(ct.Structure):
+    _fields_ = [
+        ("nrow", i64), ("nchan", i64), ("nx", i64), ("ny", i64),
+        ("pixsize_x", f64), ("pixsize_y", f64), ("center_x", f64), ("center_y", f64),
+        ("epsilon", f64), ("sigma_min", f64), ("sigma_max", f64),
+        ("flip_u", i32), ("flip_v", i32), ("flip_w", i32), ("do_wgridding", i32), ("divide_by_n", i32),
+        ("verbosity", i32), ("force_W", i32), ("force_sigma", f64),
+    ]
+
+
+class GridderInfo(ct.Structure):
+    _fields_ = [
+        ("nu", i64), ("nv", i64), ("nplanes", i64), ("nactive", i64), ("ntiles", i64), ("nwork", i64),
+        ("W", i32), ("tile", i32), ("beta", f64), ("sigma", f64), ("wmin", f64), ("dw", f64),
+        ("nshift", f64), ("lshift", f64), ("mshift", f64), ("kernel_eps", f64), ("device_bytes", ct.c_size_t),
+    ]
+
+    def asdict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class CGInfo(ct.Structure):
+    _fields_ = [("iters", i32), ("status", i32), ("eps", f64), ("phi", f64)]
+
+
+# every symbol include/pfbhip.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "pfbhip_last_error", "pfbhip_device_count", "pfbhip_set_device", "pfbhip_get_device", "pfbhip_device_name",
+    "pfbhip_mem_info", "pfbhip_resize_thread_pool", "pfbhip_thread_pool_size", "pfbhip_good_size",
+    "pfbhip_malloc", "pfbhip_free", "pfbhip_memcpy_h2d", "pfbhip_memcpy_d2h", "pfbhip_memcpy_d2d", "pfbhip_memset",
+    "pfbhip_synchronize",
+    "pfbhip_gridder_create", "pfbhip_gridder_destroy", "pfbhip_gridder_get_info", "pfbhip_gridder_get_binmap",
+    "pfbhip_gridder_vis2dirty", "pfbhip_gridder_dirty2vis", "pfbhip_gridder_grid_plane",
+    "pfbhip_gridder_set_weights", "pfbhip_gridder_hessian", "pfbhip_gridder_hessian_dev",
+    "pfbhip_gridder_degrid_dev", "pfbhip_gridder_grid_dev", "pfbhip_gridder_profile", "pfbhip_gridder_profile_get",
+    "pfbhip_gridder_cg",
+    "pfbhip_r2c_2d", "pfbhip_c2r_2d",
+    "pfbhip_psfconv_create", "pfbhip_psfconv_destroy", "pfbhip_psfconv_set_psfhat", "pfbhip_psfconv_set_beam",
+    "pfbhip_psfconv_apply", "pfbhip_psfconv_apply_dev", "pfbhip_psfconv_cg",
+    "pfbhip_uvcell_index", "pfbhip_compute_counts", "pfbhip_counts_divide",
+    "pfbhip_comm_unique_id", "pfbhip_comm_create", "pfbhip_comm_destroy", "pfbhip_comm_reduce_sum",
+    "pfbhip_comm_allreduce_sum", "pfbhip_comm_barrier",
+)
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises ImportError (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(hipcc, --offload-arch=gfx950) or `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "pfb-imaging_amd has no CPU fallback."
+            )
+        L = ct.CDLL(LIB_PATH)
+        L.pfbhip_last_error.restype = ct.c_char_p
+        L.pfbhip_good_size.restype = i64
+        L.pfbhip_good_size.argtypes = [i64, cint]
+        L.pfbhip_thread_pool_size.restype = cint
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().pfbhip_last_error().decode("utf-8", "replace")
+
+
+def check(status):
+    if status == 0:
+        return
+    msg = last_error()
+    if status == 1:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count():
+    n = cint(0)
+    check(lib().pfbhip_device_count(ct.byref(n)))
+    return n.value
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise RuntimeError("pfb-imaging_amd: no AMD GPU visible (hipGetDeviceCount == 0); there is no CPU fallback")
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    if not a.flags.c_contiguous:
+        raise ValueError("internal error: array is not C-contiguous")
+    return a.ctypes.data_as(vp)
+
+
+def as_c(a, dtype):
+    """C-contiguous array of ``dtype`` without copying when possible (inputs may be read-only views)."""
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class DeviceArray:
+    """A device allocation with numpy-like shape/dtype (host<->device copies are explicit)."""
+
+    def __init__(self, shape, dtype=np.float64):
+        self.shape = tuple(int(s) for s in (shape if np.iterable(shape) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = vp()
+        check(lib().pfbhip_malloc(ct.byref(p), ct.c_size_t(max(self.nbytes, 1))))
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        d.upload(a)
+        return d
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.nbytes == self.nbytes
+        check(lib().pfbhip_memcpy_h2d(self.ptr, ptr(a), ct.c_size_t(self.nbytes)))
+
+    def download(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        assert out.nbytes == self.nbytes and out.flags.c_contiguous
+        check(lib().pfbhip_memcpy_d2h(ptr(out), self.ptr, ct.c_size_t(self.nbytes)))
+        return out
+
+    def zero(self):
+        check(lib().pfbhip_memset(self.ptr, 0, ct.c_size_t(self.nbytes)))
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            lib().pfbhip_free(self.ptr)
+            self.ptr = vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,107 @@
+// common.hpp -- shared host-side plumbing for libpfbhip (error handling, device buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pfbhip.h"
+
+namespace pfbhip {
+
+struct InvalidArg : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+void set_last_error(const std::string &msg);
+
+inline std::string strprintf(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return std::string(buf);
+}
+
+#define PFB_HIP(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            throw std::runtime_error(pfbhip::strprintf("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                                       __FILE__, __LINE__));                              \
+    } while (0)
+
+#define PFB_REQUIRE(cond, ...)                                               \
+    do {                                                                     \
+        if (!(cond)) throw pfbhip::InvalidArg(pfbhip::strprintf(__VA_ARGS__)); \
+    } while (0)
+
+// Runs body(), converting C++ exceptions into C status codes.
+template <class F>
+int guarded(F &&body) noexcept
+{
+    try {
+        body();
+        return PFBHIP_OK;
+    } catch (const InvalidArg &e) {
+        set_last_error(e.what());
+        return PFBHIP_ERR_INVALID;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return PFBHIP_ERR_RUNTIME;
+    } catch (...) {
+        set_last_error("unknown C++ exception");
+        return PFBHIP_ERR_RUNTIME;
+    }
+}
+
+// Owning device buffer.
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept
+    {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count)
+    {
+        release();
+        if (count) PFB_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        n = count;
+    }
+    void ensure(size_t count)
+    {
+        if (count > n) alloc(count);
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+int64_t good_size_2357(int64_t n);
+int64_t good_size(int64_t n, bool real);
+
+// Gauss-Legendre nodes/weights on [-1,1].
+void gauss_legendre(int n, std::vector<double> &x, std::vector<double> &w);
+
+}  // namespace pfbhip

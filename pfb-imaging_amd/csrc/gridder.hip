@@ -1,0 +1,1102 @@
+// gridder.hip -- w-stacking gridder / degridder / exact Hessian on MI355X.
+//
+// Replaces ducc0.wgridder.experimental.vis2dirty / dirty2vis as called by the reference at
+// /root/reference/src/pfb_imaging/operators/hessian.py:50-89 and
+// /root/reference/src/pfb_imaging/operators/gridder.py:78,128,590-613,972-1016.
+//
+// Algorithm (published method: Arras et al. 2021, A&A 646 A58; ES kernel of Barnett et al. 2019):
+//   vis2dirty: weight + phase-shift + Hermitian-fold the visibilities into tile-sorted order;
+//              per w-plane: scatter with phi(u)phi(v)phi(w) (k_grid) -> backward FFT (rocFFT) ->
+//              crop, multiply by the w-screen exp(-2 pi i w_p (n-1+nshift)), accumulate Re;
+//              finally multiply by the correction image 1/(psi_l psi_m psi_n) [/n].
+//   dirty2vis: the exact adjoint, backwards.
+//   hessian:   dirty2vis then vis2dirty with the model visibilities kept on the device in
+//              tile-sorted order (no un-permute, no phase shift: they cancel).
+//
+// Compiled with -ffp-contract=off (see vismap.hpp: bit-exact index map).
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "devcg.hpp"
+#include "eskernel.hpp"
+#include "gridder_kernels.hpp"
+#include "vismap.hpp"
+
+namespace pfbhip {
+
+constexpr double SPEED_OF_LIGHT = 299792458.0;
+
+#define PFB_ROCFFT(expr)                                                                              \
+    do {                                                                                              \
+        rocfft_status _s = (expr);                                                                    \
+        if (_s != rocfft_status_success)                                                              \
+            throw std::runtime_error(pfbhip::strprintf("%s failed: rocfft status %d (%s:%d)", #expr, \
+                                                       int(_s), __FILE__, __LINE__));                 \
+    } while (0)
+
+void rocfft_setup_once();
+
+// ---------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double nm1_of(double l, double m)
+{
+    double r2 = l * l + m * m;
+    if (r2 <= 1.0) return -r2 / (1.0 + sqrt(1.0 - r2));
+    return -sqrt(r2 - 1.0) - 1.0;
+}
+
+struct ImgGeom {
+    int nx, ny, nu, nv;
+    double px, py, lshift, mshift, nshift;
+};
+
+__device__ __forceinline__ double pixel_t(const ImgGeom &g, int ix, int iy)
+{
+    double l = g.lshift + double(ix - g.nx / 2) * g.px;
+    double m = g.mshift + double(iy - g.ny / 2) * g.py;
+    return nm1_of(l, m) + g.nshift;
+}
+
+// min/max of w (>= 0 after the fold) over unmasked visibilities: one (min,max) pair per block
+__global__ void k_wrange(MapArgs m, double *out)
+{
+    __shared__ double smin[256], smax[256];
+    double lo = 1e300, hi = -1e300;
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < m.nvis; i += int64_t(gridDim.x) * blockDim.x) {
+        if (m.mask && !m.mask[i]) continue;
+        int64_t row = i / m.nchan;
+        int chan = int(i - row * m.nchan);
+        double w = fabs(m.uvw[3 * row + 2] * m.sw * m.fc[chan]);
+        lo = fmin(lo, w);
+        hi = fmax(hi, w);
+    }
+    smin[threadIdx.x] = lo;
+    smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + s]);
+            smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = smin[0];
+        out[2 * blockIdx.x + 1] = smax[0];
+    }
+}
+
+__global__ void k_keys(MapArgs m, uint32_t *keys, uint32_t *idx)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i >= m.nvis) return;
+    idx[i] = uint32_t(i);
+    if (m.mask && !m.mask[i]) {
+        keys[i] = 0xFFFFFFFFu;
+        return;
+    }
+    VisPos p = vis_position(m, i);
+    keys[i] = tile_of(m, p.iu0, p.iv0);
+}
+
+// tstart[t] = first sorted position whose key >= t  (t = 0..ntiles); tstart[ntiles] = nactive
+__global__ void k_tile_start(const uint32_t *keys, int64_t n, uint32_t ntiles, uint32_t *tstart)
+{
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > ntiles) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < t) lo = mid + 1;
+        else hi = mid;
+    }
+    tstart[t] = uint32_t(lo);
+}
+
+__global__ void k_records(MapArgs m, const uint32_t *sorted_idx, int64_t nactive, double *pu, double *pv, double *pw,
+                          uint32_t *src)
+{
+    int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (j >= nactive) return;
+    uint32_t i = sorted_idx[j];
+    VisPos p = vis_position(m, i);
+    pu[j] = p.pu;
+    pv[j] = p.pv;
+    pw[j] = p.pw;
+    src[j] = i | (uint32_t(p.flip) << 31);
+}
+
+__global__ void k_binmap(MapArgs m, int32_t *iu0, int32_t *iv0, int32_t *p0, uint8_t *flip)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i >= m.nvis) return;
+    VisPos p = vis_position(m, i);
+    iu0[i] = p.iu0;
+    iv0[i] = p.iv0;
+    p0[i] = p.p0;
+    flip[i] = uint8_t(p.flip);
+}
+
+// exp(sign * 2 pi i (u lshift + v mshift + w nshift)) for sorted visibility j
+__device__ __forceinline__ void shift_phase(const MapArgs &m, uint32_t i, double ls, double ms, double ns, double *c,
+                                            double *s)
+{
+    VisPos p = vis_position(m, i);
+    double ph = p.u * ls + p.v * ms + p.w * ns;
+    ph -= rint(ph);
+    sincospi(2.0 * ph, s, c);
+}
+
+// sval[j] = vis[src] * wgt[src] (conj if folded) * exp(+2 pi i shift phase)
+__global__ void k_permute_in(MapArgs m, const uint32_t *src, int64_t nactive, const double2 *vis, const double *wgt,
+                             int shifting, double ls, double ms, double ns, double2 *sval)
+{
+    int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (j >= nactive) return;
+    uint32_t s = src[j];
+    uint32_t i = s & 0x7FFFFFFFu;
+    double2 v = vis[i];
+    if (wgt) {
+        double w = wgt[i];
+        v.x *= w;
+        v.y *= w;
+    }
+    if (s >> 31) v.y = -v.y;
+    if (shifting) {
+        double c, sn;
+        shift_phase(m, i, ls, ms, ns, &c, &sn);
+        double re = v.x * c - v.y * sn, im = v.x * sn + v.y * c;
+        v.x = re;
+        v.y = im;
+    }
+    sval[j] = v;
+}
+
+// vis[src] = sacc[j] * exp(-2 pi i shift phase) (conj if folded) * wgt[src]
+__global__ void k_permute_out(MapArgs m, const uint32_t *src, int64_t nactive, const double2 *sacc, const double *wgt,
+                              int shifting, double ls, double ms, double ns, double2 *vis)
+{
+    int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (j >= nactive) return;
+    uint32_t s = src[j];
+    uint32_t i = s & 0x7FFFFFFFu;
+    double2 v = sacc[j];
+    if (shifting) {
+        double c, sn;
+        shift_phase(m, i, ls, ms, ns, &c, &sn);
+        double re = v.x * c + v.y * sn, im = -v.x * sn + v.y * c;
+        v.x = re;
+        v.y = im;
+    }
+    if (s >> 31) v.y = -v.y;
+    if (wgt) {
+        double w = wgt[i];
+        v.x *= w;
+        v.y *= w;
+    }
+    vis[i] = v;
+}
+
+__global__ void k_gather_f64(const uint32_t *src, int64_t nactive, const double *in, double *out)
+{
+    int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (j >= nactive) return;
+    out[j] = in ? in[src[j] & 0x7FFFFFFFu] : 1.0;
+}
+
+__global__ void k_scale_sorted(int64_t nactive, const double2 *in, const double *swgt, double2 *out)
+{
+    int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (j >= nactive) return;
+    double2 v = in[j];
+    double w = swgt[j];
+    v.x *= w;
+    v.y *= w;
+    out[j] = v;
+}
+
+// correction image: cfu[ix] cfv[iy] / psi_w(t dw) [/ n]
+__global__ void k_corr_image(ImgGeom g, const double *cfu, const double *cfv, const double *cheb, int ncheb, double dw,
+                             double zmax, int do_w, int divide_by_n, double *corr)
+{
+    int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (p >= int64_t(g.nx) * g.ny) return;
+    int ix = int(p / g.ny), iy = int(p - int64_t(ix) * g.ny);
+    double c = cfu[ix] * cfv[iy];
+    if (do_w) {
+        double t = pixel_t(g, ix, iy);
+        double z = t * dw / zmax;
+        double y = 2.0 * z * z - 1.0;
+        // Clenshaw
+        double b1 = 0.0, b2 = 0.0;
+        for (int k = ncheb - 1; k >= 1; --k) {
+            double b0 = 2.0 * y * b1 - b2 + cheb[k];
+            b2 = b1;
+            b1 = b0;
+        }
+        c *= y * b1 - b2 + cheb[0];
+        if (divide_by_n) c /= (t - g.nshift + 1.0);
+    }
+    corr[p] = c;
+}
+
+// out = a * b [* c]
+__global__ void k_mul_images(int64_t n, const double *a, const double *b, const double *c, double *out)
+{
+    int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (p >= n) return;
+    double v = a[p] * b[p];
+    if (c) v *= c[p];
+    out[p] = v;
+}
+
+// out = acc * corr [* beam] * scale + eta * x
+__global__ void k_finalize(int64_t n, const double *acc, const double *corr, const double *beam, double scale,
+                           double eta, const double *x, double *out)
+{
+    int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (p >= n) return;
+    double v = acc[p] * corr[p];
+    if (beam) v *= beam[p];
+    v *= scale;
+    if (x) v += eta * x[p];
+    out[p] = v;
+}
+
+// degrid side: grid[wrap(ix - nx/2), wrap(iy - ny/2)] = dc[ix,iy] * exp(+2 pi i w_p t), 0 elsewhere.
+// One thread per grid cell: the whole plane is written exactly once (no memset needed).
+__global__ void k_pad_screen(ImgGeom g, const double *dc, int do_w, double wplane, double2 *grid)
+{
+    int iv = blockIdx.x * blockDim.x + threadIdx.x;
+    int iu = blockIdx.y;
+    if (iv >= g.nv) return;
+    const int hx = g.nx / 2, hy = g.ny / 2;
+    int ix = -1, iy = -1;
+    if (iu < g.nx - hx) ix = iu + hx;
+    else if (iu >= g.nu - hx) ix = iu - (g.nu - hx);
+    if (iv < g.ny - hy) iy = iv + hy;
+    else if (iv >= g.nv - hy) iy = iv - (g.nv - hy);
+    double2 out = make_double2(0.0, 0.0);
+    if (ix >= 0 && iy >= 0) {
+        double val = dc[size_t(ix) * g.ny + iy];
+        if (do_w) {
+            double ph = wplane * pixel_t(g, ix, iy);
+            ph -= rint(ph);
+            double s, c;
+            sincospi(2.0 * ph, &s, &c);
+            out.x = val * c;
+            out.y = val * s;
+        } else {
+            out.x = val;
+        }
+    }
+    grid[size_t(iu) * g.nv + iv] = out;
+}
+
+// grid side: acc[ix,iy] (+)= Re( grid[wrap] * exp(-2 pi i w_p t) )
+__global__ void k_crop_screen(ImgGeom g, const double2 *grid, int do_w, double wplane, int first, double *acc)
+{
+    int iy = blockIdx.x * blockDim.x + threadIdx.x;
+    int ix = blockIdx.y;
+    if (iy >= g.ny) return;
+    const int hx = g.nx / 2, hy = g.ny / 2;
+    int iu = ix - hx;
+    if (iu < 0) iu += g.nu;
+    int iv = iy - hy;
+    if (iv < 0) iv += g.nv;
+    double2 v = grid[size_t(iu) * g.nv + iv];
+    double r;
+    if (do_w) {
+        double ph = wplane * pixel_t(g, ix, iy);
+        ph -= rint(ph);
+        double s, c;
+        sincospi(2.0 * ph, &s, &c);
+        r = v.x * c + v.y * s;
+    } else {
+        r = v.x;
+    }
+    size_t o = size_t(ix) * g.ny + iy;
+    acc[o] = first ? r : acc[o] + r;
+}
+
+// ---------------------------------------------------------------------------------------
+// the handle
+// ---------------------------------------------------------------------------------------
+
+struct StageTimer {
+    bool enabled = false;
+    hipStream_t stream = nullptr;
+    struct Rec {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double ms[PFBHIP_NSTAGES] = {0};
+    int64_t calls[PFBHIP_NSTAGES] = {0};
+    hipEvent_t get()
+    {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        PFB_HIP(hipEventCreate(&e));
+        return e;
+    }
+    void begin(int stage)
+    {
+        if (!enabled) return;
+        Rec r{stage, get(), get()};
+        PFB_HIP(hipEventRecord(r.a, stream));
+        recs.push_back(r);
+    }
+    void end()
+    {
+        if (!enabled) return;
+        PFB_HIP(hipEventRecord(recs.back().b, stream));
+    }
+    void collect()
+    {
+        for (auto &r : recs) {
+            PFB_HIP(hipEventSynchronize(r.b));
+            float t = 0;
+            PFB_HIP(hipEventElapsedTime(&t, r.a, r.b));
+            ms[r.stage] += t;
+            calls[r.stage] += 1;
+            pool.push_back(r.a);
+            pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+    ~StageTimer()
+    {
+        for (auto &r : recs) {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+}  // namespace pfbhip
+
+using namespace pfbhip;
+
+struct pfbhip_gridder {
+    pfbhip_gridder_params prm{};
+    pfbhip_gridder_info info{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t nvis = 0;
+    bool shifting = false;
+    MapArgs map{};
+    ImgGeom geom{};
+    // plan-lifetime device data
+    DevBuf<double> d_uvw, d_fc, d_pu, d_pv, d_pw, d_corr, d_cfu, d_cfv, d_cheb;
+    DevBuf<uint8_t> d_mask;
+    DevBuf<uint32_t> d_src;
+    DevBuf<WorkItem> d_work;
+    // scratch
+    DevBuf<double2> d_grid, d_sval, d_sacc, d_vis;
+    DevBuf<double> d_wgt, d_swgt, d_acc, d_img, d_img2, d_beam;
+    DevBuf<char> d_fftwork;
+    bool weights_bound = false;
+    rocfft_plan fft_fwd = nullptr, fft_bwd = nullptr;
+    rocfft_execution_info fft_info = nullptr;
+    StageTimer timer;
+
+    ~pfbhip_gridder()
+    {
+        if (fft_fwd) rocfft_plan_destroy(fft_fwd);
+        if (fft_bwd) rocfft_plan_destroy(fft_bwd);
+        if (fft_info) rocfft_execution_info_destroy(fft_info);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    size_t device_bytes() const
+    {
+        return d_uvw.bytes() + d_fc.bytes() + d_pu.bytes() + d_pv.bytes() + d_pw.bytes() + d_corr.bytes() +
+               d_cfu.bytes() + d_cfv.bytes() + d_cheb.bytes() + d_mask.bytes() + d_src.bytes() + d_work.bytes() +
+               d_grid.bytes() + d_sval.bytes() + d_sacc.bytes() + d_vis.bytes() + d_wgt.bytes() + d_swgt.bytes() +
+               d_acc.bytes() + d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes();
+    }
+
+    PlaneArgs plane_args(int plane) const
+    {
+        PlaneArgs a;
+        a.nu = int(info.nu);
+        a.nv = int(info.nv);
+        a.ntv = map.ntv;
+        a.do_w = prm.do_wgridding;
+        a.plane = plane;
+        a.beta = info.beta;
+        a.pu = d_pu.p;
+        a.pv = d_pv.p;
+        a.pw = d_pw.p;
+        a.work = d_work.p;
+        a.nwork = uint32_t(info.nwork);
+        return a;
+    }
+
+    void fft(bool forward)
+    {
+        void *buf[1] = {d_grid.p};
+        timer.begin(2);
+        PFB_ROCFFT(rocfft_execute(forward ? fft_fwd : fft_bwd, buf, nullptr, fft_info));
+        timer.end();
+    }
+
+    template <int W>
+    void launch_grid_w(int plane, const double2 *sval)
+    {
+        constexpr int L = TILE + W - 1;
+        size_t lds = size_t(2) * L * L * sizeof(double);
+        uint32_t nblk = uint32_t(ceil_div(info.nwork, 8) * 8);
+        hipLaunchKernelGGL(k_grid<W>, dim3(nblk), dim3(GRID_THREADS), lds, stream, plane_args(plane), sval, d_grid.p);
+    }
+    template <int W>
+    void launch_degrid_w(int plane, double2 *sacc)
+    {
+        constexpr int L = TILE + W - 1;
+        size_t lds = size_t(L) * L * sizeof(double2);
+        uint32_t nblk = uint32_t(ceil_div(info.nwork, 8) * 8);
+        hipLaunchKernelGGL(k_degrid<W>, dim3(nblk), dim3(GRID_THREADS), lds, stream, plane_args(plane), d_grid.p,
+                           sacc);
+    }
+#define PFB_W_DISPATCH(fn, ...)                                          \
+    switch (info.W) {                                                    \
+        case 4: fn<4>(__VA_ARGS__); break;                               \
+        case 5: fn<5>(__VA_ARGS__); break;                               \
+        case 6: fn<6>(__VA_ARGS__); break;                               \
+        case 7: fn<7>(__VA_ARGS__); break;                               \
+        case 8: fn<8>(__VA_ARGS__); break;                               \
+        case 9: fn<9>(__VA_ARGS__); break;                               \
+        case 10: fn<10>(__VA_ARGS__); break;                             \
+        case 11: fn<11>(__VA_ARGS__); break;                             \
+        case 12: fn<12>(__VA_ARGS__); break;                             \
+        case 13: fn<13>(__VA_ARGS__); break;                             \
+        case 14: fn<14>(__VA_ARGS__); break;                             \
+        case 15: fn<15>(__VA_ARGS__); break;                             \
+        case 16: fn<16>(__VA_ARGS__); break;                             \
+        default: throw std::runtime_error("unsupported kernel support"); \
+    }
+
+    // sval (tile-sorted, weighted) -> acc image (raw, before correction)
+    void grid_all_planes(const double2 *sval, double *acc)
+    {
+        const int64_t npix = int64_t(prm.nx) * prm.ny;
+        if (info.nactive == 0 || info.nwork == 0) {
+            PFB_HIP(hipMemsetAsync(acc, 0, npix * sizeof(double), stream));
+            return;
+        }
+        for (int p = 0; p < info.nplanes; ++p) {
+            timer.begin(5);
+            PFB_HIP(hipMemsetAsync(d_grid.p, 0, d_grid.bytes(), stream));
+            timer.end();
+            timer.begin(0);
+            PFB_W_DISPATCH(launch_grid_w, p, sval);
+            PFB_HIP(hipGetLastError());
+            timer.end();
+            fft(false);
+            timer.begin(4);
+            dim3 blk(256), grd(uint32_t(ceil_div(prm.ny, 256)), uint32_t(prm.nx));
+            hipLaunchKernelGGL(k_crop_screen, grd, blk, 0, stream, geom, d_grid.p, prm.do_wgridding,
+                               info.wmin + p * info.dw, p == 0 ? 1 : 0, acc);
+            PFB_HIP(hipGetLastError());
+            timer.end();
+        }
+    }
+
+    // dc image (already multiplied by the correction) -> sacc (tile-sorted)
+    void degrid_all_planes(const double *dc, double2 *sacc)
+    {
+        PFB_HIP(hipMemsetAsync(sacc, 0, size_t(std::max<int64_t>(info.nactive, 1)) * sizeof(double2), stream));
+        if (info.nactive == 0 || info.nwork == 0) return;
+        for (int p = 0; p < info.nplanes; ++p) {
+            timer.begin(3);
+            dim3 blk(256), grd(uint32_t(ceil_div(info.nv, 256)), uint32_t(info.nu));
+            hipLaunchKernelGGL(k_pad_screen, grd, blk, 0, stream, geom, dc, prm.do_wgridding,
+                               info.wmin + p * info.dw, d_grid.p);
+            PFB_HIP(hipGetLastError());
+            timer.end();
+            fft(true);
+            timer.begin(1);
+            PFB_W_DISPATCH(launch_degrid_w, p, sacc);
+            PFB_HIP(hipGetLastError());
+            timer.end();
+        }
+    }
+
+    void upload_vis_wgt(const double *vis_host, const double *wgt_host)
+    {
+        if (vis_host) {
+            d_vis.ensure(size_t(nvis));
+            PFB_HIP(hipMemcpyAsync(d_vis.p, vis_host, size_t(nvis) * sizeof(double2), hipMemcpyHostToDevice, stream));
+        }
+        if (wgt_host) {
+            d_wgt.ensure(size_t(nvis));
+            PFB_HIP(hipMemcpyAsync(d_wgt.p, wgt_host, size_t(nvis) * sizeof(double), hipMemcpyHostToDevice, stream));
+        }
+    }
+};
+
+namespace pfbhip {
+
+static inline dim3 blocks1d(int64_t n, int t = 256) { return dim3(uint32_t(std::max<int64_t>(ceil_div(n, t), 1))); }
+
+static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax)
+{
+    const auto &prm = g->prm;
+    size_t nrows = 0;
+    const KernelRow *tab = kernel_table(&nrows);
+    const double eps1 = prm.epsilon / (prm.do_wgridding ? 3.0 : 2.0);
+    const double nvis = double(g->nvis);
+    double best_cost = 1e300;
+    const KernelRow *best = nullptr;
+    int64_t bnu = 0, bnv = 0, bnpl = 1;
+    double bdw = 1.0;
+    for (size_t i = 0; i < nrows; ++i) {
+        const KernelRow &r = tab[i];
+        if (prm.force_W > 0) {
+            if (r.W != prm.force_W || std::fabs(r.sigma - prm.force_sigma) > 1e-9) continue;
+        } else {
+            if (r.sigma < prm.sigma_min - 1e-9 || r.sigma > prm.sigma_max + 1e-9 || r.eps > eps1) continue;
+        }
+        int64_t nu = grid_size(prm.nx, r.sigma), nv = grid_size(prm.ny, r.sigma);
+        double dw = 1.0;
+        int64_t npl = 1;
+        if (prm.do_wgridding && tmax > 0.0) {
+            dw = 0.5 / r.sigma / tmax;
+            npl = int64_t((whi - wlo) / dw + r.W);
+        }
+        // MI355X cost model (seconds): per plane one memset/pad + 2-D FFT + crop over the grid,
+        // ~7 passes of 16 B per cell at ~3 TB/s effective; scatter/gather ~ W^2 taps on
+        // min(W, npl) planes per visibility.
+        double cell_cost = 7.0 * 16.0 / 3.0e12;
+        double fftcost = double(npl) * double(nu) * double(nv) * cell_cost;
+        double gridcost = nvis * double(std::min<int64_t>(r.W, npl)) * (40.0 + double(r.W * r.W)) * 1.0e-12;
+        double cost = fftcost + gridcost;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = &r;
+            bnu = nu;
+            bnv = nv;
+            bnpl = npl;
+            bdw = dw;
+        }
+    }
+    PFB_REQUIRE(best != nullptr, "no ES kernel reaches epsilon=%g with sigma in [%g, %g] (double precision floor ~1e-12)",
+                prm.epsilon, prm.sigma_min, prm.sigma_max);
+    auto &info = g->info;
+    info.W = best->W;
+    info.beta = best->beta;
+    info.sigma = best->sigma;
+    info.kernel_eps = best->eps;
+    info.nu = bnu;
+    info.nv = bnv;
+    info.nplanes = bnpl;
+    info.dw = bdw;
+    info.wmin = prm.do_wgridding ? 0.5 * (wlo + whi) - 0.5 * double(bnpl - 1) * bdw : 0.0;
+    info.tile = TILE;
+}
+
+static void nm1_range(const pfbhip_gridder_params &p, double lshift, double mshift, double *lo, double *hi)
+{
+    // corners of the pixel-centre lattice plus axis crossings (cf. oracle/wgridder.py: nm1_range)
+    double x0 = lshift - 0.5 * double(p.nx) * p.pixsize_x, y0 = mshift - 0.5 * double(p.ny) * p.pixsize_y;
+    std::vector<double> xs{x0, x0 + double(p.nx - 1) * p.pixsize_x}, ys{y0, y0 + double(p.ny - 1) * p.pixsize_y};
+    if (xs[0] * xs[1] < 0) xs.push_back(0.0);
+    if (ys[0] * ys[1] < 0) ys.push_back(0.0);
+    *lo = 1e300;
+    *hi = -1e300;
+    for (double xc : xs)
+        for (double yc : ys) {
+            double t = xc * xc + yc * yc;
+            double v = t <= 1.0 ? -t / (1.0 + std::sqrt(1.0 - t)) : -std::sqrt(t - 1.0) - 1.0;
+            *lo = std::min(*lo, v);
+            *hi = std::max(*hi, v);
+        }
+}
+
+static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq, const uint8_t *mask)
+{
+    auto &prm = g->prm;
+    PFB_REQUIRE(prm.nrow >= 0 && prm.nchan >= 1, "bad visibility shape (%lld, %lld)", (long long)prm.nrow,
+                (long long)prm.nchan);
+    PFB_REQUIRE(prm.nx >= 2 && prm.ny >= 2 && prm.nx <= 65536 && prm.ny <= 65536, "bad image shape (%lld, %lld)",
+                (long long)prm.nx, (long long)prm.ny);
+    PFB_REQUIRE(prm.pixsize_x > 0 && prm.pixsize_y > 0, "pixel sizes must be positive");
+    PFB_REQUIRE(prm.epsilon > 0 && prm.epsilon < 1, "epsilon must be in (0,1)");
+    PFB_REQUIRE(prm.nchan < (1 << 16), "too many channels");
+    g->nvis = prm.nrow * prm.nchan;
+    PFB_REQUIRE(g->nvis < (int64_t(1) << 31), "too many visibilities per handle (%lld >= 2^31)", (long long)g->nvis);
+    PFB_REQUIRE(uvw != nullptr || prm.nrow == 0, "uvw is NULL");
+    PFB_REQUIRE(freq != nullptr, "freq is NULL");
+
+    PFB_HIP(hipGetDevice(&g->device));
+    PFB_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    g->timer.stream = g->stream;
+    hipStream_t st = g->stream;
+    auto &info = g->info;
+
+    // geometry
+    info.lshift = prm.flip_u ? -prm.center_x : prm.center_x;
+    info.mshift = prm.flip_v ? -prm.center_y : prm.center_y;
+    double nm1min, nm1max;
+    nm1_range(prm, info.lshift, info.mshift, &nm1min, &nm1max);
+    info.nshift = prm.do_wgridding ? -0.5 * (nm1max + nm1min) : 0.0;
+    const double tmax = std::max(std::fabs(nm1max + info.nshift), std::fabs(nm1min + info.nshift));
+    g->shifting = (info.lshift != 0.0) || (info.mshift != 0.0) || (info.nshift != 0.0);
+
+    // upload uvw / fc / mask
+    const size_t nrow1 = size_t(std::max<int64_t>(prm.nrow, 1));
+    g->d_uvw.alloc(nrow1 * 3);
+    if (prm.nrow) PFB_HIP(hipMemcpyAsync(g->d_uvw.p, uvw, size_t(prm.nrow) * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    std::vector<double> fc(prm.nchan);
+    for (int64_t c = 0; c < prm.nchan; ++c) fc[c] = freq[c] / SPEED_OF_LIGHT;
+    g->d_fc.alloc(size_t(prm.nchan));
+    PFB_HIP(hipMemcpyAsync(g->d_fc.p, fc.data(), fc.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    if (mask && g->nvis) {
+        g->d_mask.alloc(size_t(g->nvis));
+        PFB_HIP(hipMemcpyAsync(g->d_mask.p, mask, size_t(g->nvis), hipMemcpyHostToDevice, st));
+    }
+
+    MapArgs &m = g->map;
+    m.uvw = g->d_uvw.p;
+    m.fc = g->d_fc.p;
+    m.mask = g->d_mask.p;
+    m.nvis = g->nvis;
+    m.nchan = int(prm.nchan);
+    m.su = prm.flip_u ? -1.0 : 1.0;
+    m.sv = prm.flip_v ? -1.0 : 1.0;
+    m.sw = prm.flip_w ? -1.0 : 1.0;
+    m.px = prm.pixsize_x;
+    m.py = prm.pixsize_y;
+    m.do_w = prm.do_wgridding;
+
+    // w range over unmasked visibilities
+    double wlo = 0.0, whi = 0.0;
+    if (prm.do_wgridding && g->nvis > 0) {
+        const int nb = 512;
+        DevBuf<double> d_mm(2 * nb);
+        hipLaunchKernelGGL(k_wrange, dim3(nb), dim3(256), 0, st, m, d_mm.p);
+        PFB_HIP(hipGetLastError());
+        std::vector<double> mm(2 * nb);
+        PFB_HIP(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipStreamSynchronize(st));
+        wlo = 1e300;
+        whi = -1e300;
+        for (int b = 0; b < nb; ++b) {
+            wlo = std::min(wlo, mm[2 * b]);
+            whi = std::max(whi, mm[2 * b + 1]);
+        }
+        if (wlo > whi) wlo = whi = 0.0;  // everything masked
+    }
+
+    choose_kernel(g, wlo, whi, tmax);
+    PFB_REQUIRE(info.nplanes >= 1 && info.nplanes < 100000, "unreasonable number of w-planes (%lld)",
+                (long long)info.nplanes);
+
+    m.nu = int(info.nu);
+    m.nv = int(info.nv);
+    m.dnu = double(info.nu);
+    m.dnv = double(info.nv);
+    m.ntv = int(ceil_div(info.nv, TILE));
+    m.W = info.W;
+    m.shift = 1.0 - 0.5 * double(info.W);
+    m.wmin = info.wmin;
+    m.xdw = 1.0 / info.dw;
+    const int64_t ntu = ceil_div(info.nu, TILE);
+    info.ntiles = ntu * m.ntv;
+
+    g->geom = ImgGeom{int(prm.nx), int(prm.ny), int(info.nu), int(info.nv), prm.pixsize_x, prm.pixsize_y,
+                      info.lshift, info.mshift, info.nshift};
+
+    // ---- tile sort of the unmasked visibilities ----
+    std::vector<WorkItem> work;
+    info.nactive = 0;
+    if (g->nvis > 0) {
+        DevBuf<uint32_t> k_in(size_t(g->nvis)), k_out(size_t(g->nvis)), v_in(size_t(g->nvis)), v_out(size_t(g->nvis));
+        hipLaunchKernelGGL(k_keys, blocks1d(g->nvis), dim3(256), 0, st, m, k_in.p, v_in.p);
+        PFB_HIP(hipGetLastError());
+        size_t tmp_bytes = 0;
+        PFB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in.p, k_out.p, v_in.p, v_out.p, int(g->nvis), 0,
+                                                   32, st));
+        DevBuf<char> tmp(tmp_bytes);
+        PFB_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k_in.p, k_out.p, v_in.p, v_out.p, int(g->nvis), 0,
+                                                   32, st));
+        DevBuf<uint32_t> d_tstart(size_t(info.ntiles) + 1);
+        hipLaunchKernelGGL(k_tile_start, blocks1d(info.ntiles + 1), dim3(256), 0, st, k_out.p, g->nvis,
+                           uint32_t(info.ntiles), d_tstart.p);
+        PFB_HIP(hipGetLastError());
+        std::vector<uint32_t> tstart(size_t(info.ntiles) + 1);
+        PFB_HIP(hipMemcpyAsync(tstart.data(), d_tstart.p, tstart.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipStreamSynchronize(st));
+        info.nactive = tstart[size_t(info.ntiles)];
+        for (int64_t t = 0; t < info.ntiles; ++t)
+            for (uint32_t b = tstart[t]; b < tstart[t + 1]; b += CHUNK)
+                work.push_back(WorkItem{uint32_t(t), b, std::min<uint32_t>(b + CHUNK, tstart[t + 1]), 0});
+        const size_t na1 = size_t(std::max<int64_t>(info.nactive, 1));
+        g->d_pu.alloc(na1);
+        g->d_pv.alloc(na1);
+        g->d_pw.alloc(na1);
+        g->d_src.alloc(na1);
+        if (info.nactive) {
+            hipLaunchKernelGGL(k_records, blocks1d(info.nactive), dim3(256), 0, st, m, v_out.p, info.nactive, g->d_pu.p,
+                               g->d_pv.p, g->d_pw.p, g->d_src.p);
+            PFB_HIP(hipGetLastError());
+        }
+        PFB_HIP(hipStreamSynchronize(st));
+    }
+    info.nwork = int64_t(work.size());
+    g->d_work.alloc(std::max<size_t>(work.size(), 1));
+    if (!work.empty())
+        PFB_HIP(hipMemcpyAsync(g->d_work.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice, st));
+
+    // ---- correction image ----
+    const int64_t npix = prm.nx * prm.ny;
+    KernelFT ft(info.W, info.beta);
+    std::vector<double> cfu = ft.correction_1d(prm.nx, info.nu), cfv = ft.correction_1d(prm.ny, info.nv);
+    g->d_cfu.alloc(cfu.size());
+    g->d_cfv.alloc(cfv.size());
+    PFB_HIP(hipMemcpyAsync(g->d_cfu.p, cfu.data(), cfu.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    PFB_HIP(hipMemcpyAsync(g->d_cfv.p, cfv.data(), cfv.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    std::vector<double> cheb{1.0};
+    double zmax = 1.0;
+    if (prm.do_wgridding && tmax > 0.0) {
+        zmax = tmax * info.dw * (1.0 + 1e-12);
+        cheb = ft.inverse_cheb(zmax);
+    }
+    g->d_cheb.alloc(cheb.size());
+    PFB_HIP(hipMemcpyAsync(g->d_cheb.p, cheb.data(), cheb.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    g->d_corr.alloc(size_t(npix));
+    hipLaunchKernelGGL(k_corr_image, blocks1d(npix), dim3(256), 0, st, g->geom, g->d_cfu.p, g->d_cfv.p, g->d_cheb.p,
+                       int(cheb.size()), info.dw, zmax, prm.do_wgridding && tmax > 0.0 ? 1 : 0, prm.divide_by_n,
+                       g->d_corr.p);
+    PFB_HIP(hipGetLastError());
+
+    // ---- scratch + FFT plans ----
+    g->d_grid.alloc(size_t(info.nu) * size_t(info.nv));
+    g->d_acc.alloc(size_t(npix));
+    g->d_img.alloc(size_t(npix));
+    g->d_sval.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
+    g->d_sacc.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
+
+    rocfft_setup_once();
+    size_t lengths[2] = {size_t(info.nv), size_t(info.nu)};  // fastest first
+    PFB_ROCFFT(rocfft_plan_create(&g->fft_fwd, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
+                                  rocfft_precision_double, 2, lengths, 1, nullptr));
+    PFB_ROCFFT(rocfft_plan_create(&g->fft_bwd, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                                  rocfft_precision_double, 2, lengths, 1, nullptr));
+    size_t wf = 0, wb = 0;
+    PFB_ROCFFT(rocfft_plan_get_work_buffer_size(g->fft_fwd, &wf));
+    PFB_ROCFFT(rocfft_plan_get_work_buffer_size(g->fft_bwd, &wb));
+    PFB_ROCFFT(rocfft_execution_info_create(&g->fft_info));
+    size_t wmax = std::max(wf, wb);
+    if (wmax) {
+        g->d_fftwork.alloc(wmax);
+        PFB_ROCFFT(rocfft_execution_info_set_work_buffer(g->fft_info, g->d_fftwork.p, wmax));
+    }
+    PFB_ROCFFT(rocfft_execution_info_set_stream(g->fft_info, st));
+    PFB_HIP(hipStreamSynchronize(st));
+    info.device_bytes = g->device_bytes();
+}
+
+}  // namespace pfbhip
+
+// ---------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------
+
+extern "C" {
+
+int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw_host, const double *freq_host,
+                          const uint8_t *mask_host, pfbhip_gridder **out)
+{
+    return guarded([&] {
+        PFB_REQUIRE(params && out, "NULL argument");
+        std::unique_ptr<pfbhip_gridder> g(new pfbhip_gridder);
+        g->prm = *params;
+        create_impl(g.get(), uvw_host, freq_host, mask_host);
+        *out = g.release();
+    });
+}
+
+int pfbhip_gridder_destroy(pfbhip_gridder *g)
+{
+    return guarded([&] { delete g; });
+}
+
+int pfbhip_gridder_get_info(const pfbhip_gridder *g, pfbhip_gridder_info *info)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && info, "NULL argument");
+        *info = g->info;
+        info->device_bytes = g->device_bytes();
+    });
+}
+
+int pfbhip_gridder_get_binmap(pfbhip_gridder *g, int32_t *iu0, int32_t *iv0, int32_t *p0, uint8_t *flip, int64_t *order)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g, "NULL handle");
+        hipStream_t st = g->stream;
+        const int64_t n = g->nvis;
+        if (n && (iu0 || iv0 || p0 || flip)) {
+            DevBuf<int32_t> a(n), b(n), c(n);
+            DevBuf<uint8_t> f(n);
+            hipLaunchKernelGGL(k_binmap, blocks1d(n), dim3(256), 0, st, g->map, a.p, b.p, c.p, f.p);
+            PFB_HIP(hipGetLastError());
+            if (iu0) PFB_HIP(hipMemcpyAsync(iu0, a.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (iv0) PFB_HIP(hipMemcpyAsync(iv0, b.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (p0) PFB_HIP(hipMemcpyAsync(p0, c.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (flip) PFB_HIP(hipMemcpyAsync(flip, f.p, n, hipMemcpyDeviceToHost, st));
+            PFB_HIP(hipStreamSynchronize(st));
+        }
+        if (order && g->info.nactive) {
+            std::vector<uint32_t> src(size_t(g->info.nactive));
+            PFB_HIP(hipMemcpy(src.data(), g->d_src.p, src.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (size_t j = 0; j < src.size(); ++j) order[j] = int64_t(src[j] & 0x7FFFFFFFu);
+        }
+    });
+}
+
+int pfbhip_gridder_vis2dirty(pfbhip_gridder *g, const double *vis_host, const double *wgt_host, double *dirty_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && dirty_host && (vis_host || g->nvis == 0), "NULL argument");
+        hipStream_t st = g->stream;
+        const int64_t npix = g->prm.nx * g->prm.ny;
+        g->upload_vis_wgt(vis_host, wgt_host);
+        if (g->info.nactive)
+            hipLaunchKernelGGL(k_permute_in, blocks1d(g->info.nactive), dim3(256), 0, st, g->map, g->d_src.p,
+                               g->info.nactive, g->d_vis.p, wgt_host ? g->d_wgt.p : nullptr, int(g->shifting),
+                               g->info.lshift, g->info.mshift, g->info.nshift, g->d_sval.p);
+        PFB_HIP(hipGetLastError());
+        g->grid_all_planes(g->d_sval.p, g->d_acc.p);
+        hipLaunchKernelGGL(k_finalize, blocks1d(npix), dim3(256), 0, st, npix, g->d_acc.p, g->d_corr.p,
+                           (const double *)nullptr, 1.0, 0.0, (const double *)nullptr, g->d_img.p);
+        PFB_HIP(hipGetLastError());
+        PFB_HIP(hipMemcpyAsync(dirty_host, g->d_img.p, size_t(npix) * sizeof(double), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int pfbhip_gridder_grid_plane(pfbhip_gridder *g, const double *vis_host, const double *wgt_host, int64_t plane,
+                              double *grid_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && grid_host && vis_host, "NULL argument");
+        PFB_REQUIRE(plane >= 0 && plane < g->info.nplanes, "plane %lld out of range", (long long)plane);
+        hipStream_t st = g->stream;
+        g->upload_vis_wgt(vis_host, wgt_host);
+        PFB_HIP(hipMemsetAsync(g->d_grid.p, 0, g->d_grid.bytes(), st));
+        if (g->info.nactive && g->info.nwork) {
+            hipLaunchKernelGGL(k_permute_in, blocks1d(g->info.nactive), dim3(256), 0, st, g->map, g->d_src.p,
+                               g->info.nactive, g->d_vis.p, wgt_host ? g->d_wgt.p : nullptr, int(g->shifting),
+                               g->info.lshift, g->info.mshift, g->info.nshift, g->d_sval.p);
+            PFB_HIP(hipGetLastError());
+            auto &info = g->info;
+            switch (info.W) {
+#define PFB_CASE(w) case w: g->launch_grid_w<w>(int(plane), g->d_sval.p); break;
+                PFB_CASE(4) PFB_CASE(5) PFB_CASE(6) PFB_CASE(7) PFB_CASE(8) PFB_CASE(9) PFB_CASE(10) PFB_CASE(11)
+                PFB_CASE(12) PFB_CASE(13) PFB_CASE(14) PFB_CASE(15) PFB_CASE(16)
+#undef PFB_CASE
+                default: throw std::runtime_error("unsupported kernel support");
+            }
+            PFB_HIP(hipGetLastError());
+        }
+        PFB_HIP(hipMemcpyAsync(grid_host, g->d_grid.p, g->d_grid.bytes(), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int pfbhip_gridder_dirty2vis(pfbhip_gridder *g, const double *dirty_host, const double *wgt_host, double *vis_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && dirty_host && (vis_host || g->nvis == 0), "NULL argument");
+        hipStream_t st = g->stream;
+        const int64_t npix = g->prm.nx * g->prm.ny;
+        PFB_HIP(hipMemcpyAsync(g->d_img.p, dirty_host, size_t(npix) * sizeof(double), hipMemcpyHostToDevice, st));
+        g->upload_vis_wgt(nullptr, wgt_host);
+        hipLaunchKernelGGL(k_mul_images, blocks1d(npix), dim3(256), 0, st, npix, g->d_img.p, g->d_corr.p,
+                           (const double *)nullptr, g->d_acc.p);
+        PFB_HIP(hipGetLastError());
+        g->degrid_all_planes(g->d_acc.p, g->d_sacc.p);
+        if (g->nvis) {
+            g->d_vis.ensure(size_t(g->nvis));
+            PFB_HIP(hipMemsetAsync(g->d_vis.p, 0, size_t(g->nvis) * sizeof(double2), st));
+            if (g->info.nactive)
+                hipLaunchKernelGGL(k_permute_out, blocks1d(g->info.nactive), dim3(256), 0, st, g->map, g->d_src.p,
+                                   g->info.nactive, g->d_sacc.p, wgt_host ? g->d_wgt.p : nullptr, int(g->shifting),
+                                   g->info.lshift, g->info.mshift, g->info.nshift, g->d_vis.p);
+            PFB_HIP(hipGetLastError());
+            PFB_HIP(hipMemcpyAsync(vis_host, g->d_vis.p, size_t(g->nvis) * sizeof(double2), hipMemcpyDeviceToHost, st));
+        }
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int pfbhip_gridder_set_weights(pfbhip_gridder *g, const double *wgt_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g, "NULL handle");
+        hipStream_t st = g->stream;
+        g->upload_vis_wgt(nullptr, wgt_host);
+        g->d_swgt.ensure(size_t(std::max<int64_t>(g->info.nactive, 1)));
+        if (g->info.nactive)
+            hipLaunchKernelGGL(k_gather_f64, blocks1d(g->info.nactive), dim3(256), 0, st, g->d_src.p, g->info.nactive,
+                               wgt_host ? g->d_wgt.p : nullptr, g->d_swgt.p);
+        PFB_HIP(hipGetLastError());
+        PFB_HIP(hipStreamSynchronize(st));
+        g->weights_bound = true;
+    });
+}
+
+static void hessian_dev_impl(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta, double wsum,
+                             double *out_dev)
+{
+    PFB_REQUIRE(g->weights_bound, "call pfbhip_gridder_set_weights before the Hessian");
+    hipStream_t st = g->stream;
+    const int64_t npix = g->prm.nx * g->prm.ny;
+    g->timer.begin(5);
+    hipLaunchKernelGGL(k_mul_images, blocks1d(npix), dim3(256), 0, st, npix, x_dev, g->d_corr.p, beam_dev, g->d_acc.p);
+    PFB_HIP(hipGetLastError());
+    g->timer.end();
+    g->degrid_all_planes(g->d_acc.p, g->d_sacc.p);
+    g->timer.begin(5);
+    if (g->info.nactive)
+        hipLaunchKernelGGL(k_scale_sorted, blocks1d(g->info.nactive), dim3(256), 0, st, g->info.nactive, g->d_sacc.p,
+                           g->d_swgt.p, g->d_sval.p);
+    PFB_HIP(hipGetLastError());
+    g->timer.end();
+    g->grid_all_planes(g->d_sval.p, g->d_acc.p);
+    g->timer.begin(5);
+    hipLaunchKernelGGL(k_finalize, blocks1d(npix), dim3(256), 0, st, npix, g->d_acc.p, g->d_corr.p, beam_dev,
+                       wsum > 0.0 ? 1.0 / wsum : 1.0, eta, eta != 0.0 ? x_dev : nullptr, out_dev);
+    PFB_HIP(hipGetLastError());
+    g->timer.end();
+}
+
+int pfbhip_gridder_hessian_dev(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta, double wsum,
+                               double *out_dev)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && x_dev && out_dev, "NULL argument");
+        PFB_REQUIRE(x_dev != out_dev, "in-place Hessian is not supported");
+        hessian_dev_impl(g, x_dev, beam_dev, eta, wsum, out_dev);
+        PFB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+
+int pfbhip_gridder_hessian(pfbhip_gridder *g, const double *x_host, const double *beam_host, double eta, double wsum,
+                           double *out_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && x_host && out_host, "NULL argument");
+        hipStream_t st = g->stream;
+        const size_t npix = size_t(g->prm.nx * g->prm.ny);
+        g->d_img.ensure(npix);
+        g->d_img2.ensure(npix);
+        PFB_HIP(hipMemcpyAsync(g->d_img.p, x_host, npix * sizeof(double), hipMemcpyHostToDevice, st));
+        if (beam_host) {
+            g->d_beam.ensure(npix);
+            PFB_HIP(hipMemcpyAsync(g->d_beam.p, beam_host, npix * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        hessian_dev_impl(g, g->d_img.p, beam_host ? g->d_beam.p : nullptr, eta, wsum, g->d_img2.p);
+        PFB_HIP(hipMemcpyAsync(out_host, g->d_img2.p, npix * sizeof(double), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int pfbhip_gridder_cg(pfbhip_gridder *g, const double *beam_host, double eta, double wsum, const double *rhs_host,
+                      double *x_host, int has_x0, double tol, int maxit, int minit, pfbhip_cg_info *info)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && rhs_host && x_host, "NULL argument");
+        PFB_REQUIRE(g->weights_bound, "call pfbhip_gridder_set_weights before the CG solve");
+        hipStream_t st = g->stream;
+        const int64_t npix = g->prm.nx * g->prm.ny;
+        DevBuf<double> b{size_t(npix)}, x{size_t(npix)};
+        PFB_HIP(hipMemcpyAsync(b.p, rhs_host, size_t(npix) * sizeof(double), hipMemcpyHostToDevice, st));
+        if (has_x0) PFB_HIP(hipMemcpyAsync(x.p, x_host, size_t(npix) * sizeof(double), hipMemcpyHostToDevice, st));
+        else PFB_HIP(hipMemsetAsync(x.p, 0, size_t(npix) * sizeof(double), st));
+        const double *beam = nullptr;
+        if (beam_host) {
+            g->d_beam.ensure(size_t(npix));
+            PFB_HIP(hipMemcpyAsync(g->d_beam.p, beam_host, size_t(npix) * sizeof(double), hipMemcpyHostToDevice, st));
+            beam = g->d_beam.p;
+        }
+        DevCG cg(npix, st);
+        cg.solve([&](const double *in, double *out) { hessian_dev_impl(g, in, beam, eta, wsum, out); }, b.p, x.p, tol,
+                 maxit, minit, info);
+        PFB_HIP(hipMemcpyAsync(x_host, x.p, size_t(npix) * sizeof(double), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int pfbhip_gridder_degrid_dev(pfbhip_gridder *g, const double *dirty_dev, double *vis_sorted_dev)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && dirty_dev && vis_sorted_dev, "NULL argument");
+        const int64_t npix = g->prm.nx * g->prm.ny;
+        hipLaunchKernelGGL(k_mul_images, blocks1d(npix), dim3(256), 0, g->stream, npix, dirty_dev, g->d_corr.p,
+                           (const double *)nullptr, g->d_acc.p);
+        PFB_HIP(hipGetLastError());
+        g->degrid_all_planes(g->d_acc.p, reinterpret_cast<double2 *>(vis_sorted_dev));
+        PFB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+
+int pfbhip_gridder_grid_dev(pfbhip_gridder *g, const double *vis_sorted_dev, double *dirty_dev)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && dirty_dev && vis_sorted_dev, "NULL argument");
+        const int64_t npix = g->prm.nx * g->prm.ny;
+        g->grid_all_planes(reinterpret_cast<const double2 *>(vis_sorted_dev), g->d_acc.p);
+        hipLaunchKernelGGL(k_finalize, blocks1d(npix), dim3(256), 0, g->stream, npix, g->d_acc.p, g->d_corr.p,
+                           (const double *)nullptr, 1.0, 0.0, (const double *)nullptr, dirty_dev);
+        PFB_HIP(hipGetLastError());
+        PFB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+
+int pfbhip_gridder_profile(pfbhip_gridder *g, int enable)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g, "NULL handle");
+        g->timer.collect();
+        g->timer.enabled = enable != 0;
+    });
+}
+
+int pfbhip_gridder_profile_get(pfbhip_gridder *g, double *ms, int64_t *calls, int reset)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g, "NULL handle");
+        g->timer.collect();
+        for (int s = 0; s < PFBHIP_NSTAGES; ++s) {
+            if (ms) ms[s] = g->timer.ms[s];
+            if (calls) calls[s] = g->timer.calls[s];
+            if (reset) {
+                g->timer.ms[s] = 0;
+                g->timer.calls[s] = 0;
+            }
+        }
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+// weighting.hip -- uv-cell index map, counts scatter and Briggs gather-divide on MI355X.
+//
+// Replaces the numba kernels _compute_counts / counts_to_weights of
+// /root/reference/src/pfb_imaging/utils/weighting.py:81-140,143-208.
+// The integer cell index is bit-exact against the CPU oracle (oracle/pfb_oracle.c:
+// pfbo_uvcell_index): identical un-fused IEEE double sequence, compiled -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace pfbhip {
+
+constexpr double SPEED_OF_LIGHT = 299792458.0;
+
+struct CellArgs {
+    const double *uvw, *freq;
+    const uint8_t *mask;
+    int64_t nvis;
+    int nchan;
+    int64_t nx, ny;
+    double u_cell, umax, v_cell, vmax, usign, vsign;
+};
+
+__device__ __forceinline__ int64_t uv_cell(const CellArgs &a, int64_t i)
+{
+    if (!a.mask[i]) return -1;
+    int64_t r = i / a.nchan;
+    int f = int(i - r * a.nchan);
+    double nf = a.freq[f] / SPEED_OF_LIGHT;
+    double u = a.uvw[3 * r] * nf;
+    u = u * a.usign;
+    double v = a.uvw[3 * r + 1] * nf;
+    v = v * a.vsign;
+    if (v < 0.0) {
+        u = -u;
+        v = -v;
+    }
+    double ug = (u + a.umax) / a.u_cell;
+    double vg = (v + a.vmax) / a.v_cell;
+    double fu = floor(ug), fv = floor(vg);
+    if (!(fu >= 0.0) || !(fu < double(a.nx)) || !(fv >= 0.0) || !(fv < double(a.ny))) return -1;
+    return int64_t(fu) * a.ny + int64_t(fv);
+}
+
+__global__ void k_uvcell(CellArgs a, int64_t *cell)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i < a.nvis) cell[i] = uv_cell(a, i);
+}
+
+__global__ void k_counts(CellArgs a, const double *wgt, int ncorr, double *counts)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i >= a.nvis) return;
+    int64_t c = uv_cell(a, i);
+    if (c < 0) return;
+    for (int k = 0; k < ncorr; ++k) unsafeAtomicAdd(&counts[size_t(k) * a.nx * a.ny + c], wgt[size_t(k) * a.nvis + i]);
+}
+
+__global__ void k_counts_divide(CellArgs a, const double *counts, int ncorr, double *wgt)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i >= a.nvis) return;
+    int64_t c = uv_cell(a, i);
+    if (c < 0) return;
+    for (int k = 0; k < ncorr; ++k) {
+        double cv = counts[size_t(k) * a.nx * a.ny + c];
+        if (cv > 0.0) wgt[size_t(k) * a.nvis + i] /= cv;
+    }
+}
+
+struct CellSetup {
+    DevBuf<double> uvw, freq;
+    DevBuf<uint8_t> mask;
+    CellArgs a;
+    CellSetup(const double *uvw_h, const double *freq_h, const uint8_t *mask_h, int64_t nrow, int64_t nchan, int64_t nx,
+              int64_t ny, double cell_x, double cell_y, double usign, double vsign)
+    {
+        PFB_REQUIRE(uvw_h && freq_h && mask_h, "NULL argument");
+        PFB_REQUIRE(nrow >= 0 && nchan >= 1 && nx >= 1 && ny >= 1, "bad shapes");
+        uvw.alloc(size_t(std::max<int64_t>(nrow, 1)) * 3);
+        freq.alloc(size_t(nchan));
+        mask.alloc(size_t(std::max<int64_t>(nrow * nchan, 1)));
+        PFB_HIP(hipMemcpy(uvw.p, uvw_h, size_t(nrow) * 3 * sizeof(double), hipMemcpyHostToDevice));
+        PFB_HIP(hipMemcpy(freq.p, freq_h, size_t(nchan) * sizeof(double), hipMemcpyHostToDevice));
+        PFB_HIP(hipMemcpy(mask.p, mask_h, size_t(nrow * nchan), hipMemcpyHostToDevice));
+        a.uvw = uvw.p;
+        a.freq = freq.p;
+        a.mask = mask.p;
+        a.nvis = nrow * nchan;
+        a.nchan = int(nchan);
+        a.nx = nx;
+        a.ny = ny;
+        // same expressions as weighting.py:84-90
+        a.u_cell = 1.0 / (double(nx) * cell_x);
+        a.umax = std::fabs(1.0 / cell_x / 2.0);
+        a.v_cell = 1.0 / (double(ny) * cell_y);
+        a.vmax = std::fabs(1.0 / cell_y / 2.0);
+        a.usign = usign;
+        a.vsign = vsign;
+    }
+    dim3 grid() const { return dim3(uint32_t(std::max<int64_t>(ceil_div(a.nvis, 256), 1))); }
+};
+
+}  // namespace pfbhip
+
+using namespace pfbhip;
+
+extern "C" {
+
+int pfbhip_uvcell_index(const double *uvw_host, const double *freq_host, const uint8_t *mask_host, int64_t nrow,
+                        int64_t nchan, int64_t nx, int64_t ny, double cell_x, double cell_y, double usign, double vsign,
+                        int64_t *cell_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(cell_host, "NULL argument");
+        CellSetup s(uvw_host, freq_host, mask_host, nrow, nchan, nx, ny, cell_x, cell_y, usign, vsign);
+        if (!s.a.nvis) return;
+        DevBuf<int64_t> cell(size_t(s.a.nvis));
+        hipLaunchKernelGGL(k_uvcell, s.grid(), dim3(256), 0, 0, s.a, cell.p);
+        PFB_HIP(hipGetLastError());
+        PFB_HIP(hipMemcpy(cell_host, cell.p, cell.bytes(), hipMemcpyDeviceToHost));
+    });
+}
+
+int pfbhip_compute_counts(const double *uvw_host, const double *freq_host, const uint8_t *mask_host,
+                          const double *wgt_host, int64_t ncorr, int64_t nrow, int64_t nchan, int64_t nx, int64_t ny,
+                          double cell_x, double cell_y, double usign, double vsign, double *counts_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(wgt_host && counts_host && ncorr >= 1, "NULL argument");
+        CellSetup s(uvw_host, freq_host, mask_host, nrow, nchan, nx, ny, cell_x, cell_y, usign, vsign);
+        size_t ncnt = size_t(ncorr) * size_t(nx) * size_t(ny);
+        DevBuf<double> counts(ncnt);
+        PFB_HIP(hipMemcpy(counts.p, counts_host, counts.bytes(), hipMemcpyHostToDevice));
+        if (s.a.nvis) {
+            DevBuf<double> wgt(size_t(ncorr) * size_t(s.a.nvis));
+            PFB_HIP(hipMemcpy(wgt.p, wgt_host, wgt.bytes(), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_counts, s.grid(), dim3(256), 0, 0, s.a, wgt.p, int(ncorr), counts.p);
+            PFB_HIP(hipGetLastError());
+        }
+        PFB_HIP(hipMemcpy(counts_host, counts.p, counts.bytes(), hipMemcpyDeviceToHost));
+    });
+}
+
+int pfbhip_counts_divide(const double *uvw_host, const double *freq_host, const uint8_t *mask_host,
+                         const double *counts_host, int64_t ncorr, int64_t nrow, int64_t nchan, int64_t nx, int64_t ny,
+                         double cell_x, double cell_y, double usign, double vsign, double *wgt_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(wgt_host && counts_host && ncorr >= 1, "NULL argument");
+        CellSetup s(uvw_host, freq_host, mask_host, nrow, nchan, nx, ny, cell_x, cell_y, usign, vsign);
+        if (!s.a.nvis) return;
+        DevBuf<double> counts(size_t(ncorr) * size_t(nx) * size_t(ny)), wgt(size_t(ncorr) * size_t(s.a.nvis));
+        PFB_HIP(hipMemcpy(counts.p, counts_host, counts.bytes(), hipMemcpyHostToDevice));
+        PFB_HIP(hipMemcpy(wgt.p, wgt_host, wgt.bytes(), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_counts_divide, s.grid(), dim3(256), 0, 0, s.a, counts.p, int(ncorr), wgt.p);
+        PFB_HIP(hipGetLastError());
+        PFB_HIP(hipMemcpy(wgt_host, wgt.p, wgt.bytes(), hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+"""Per-band worker co-locating a band's deconvolution state on its GPU.
+
+Mirrors /root/reference/src/pfb_imaging/operators/band_worker.py:23-319.  The reference runs
+one Ray actor per band; here a band is owned by one GPU process (``parallel.BandComm``:
+band ``b`` -> rank ``b % world_size``), holding its HessianTree (PSFs/beams resident in HBM,
+CG on the device) and its gridding inputs (tile-sorted visibilities resident in HBM) for the
+exact residual.  ``BandWorkerPool`` keeps the reference's cube-level methods; with a
+communicator every rank calls them collectively (SPMD) and per-band results are exchanged
+with one RCCL all-reduce of the cube (each band is produced by exactly one rank), while
+``residual_mfs`` uses the RCCL sum-to-root that replaces the driver-side band sum
+(core/deconv.py:320-321).  Without a communicator all bands run in-process on the current
+GPU, like the reference's ``nband == 1`` local path (band_worker.py:220-223).
+
+The wavelet role (``init_psi`` / ``psi_dot`` / ``psi_hdot``) belongs to the SARA dictionary,
+which SURVEY.md section 8(f) ranks after this path; it raises NotImplementedError.
+"""
+
+import numpy as np
+
+from .. import _lib
+from ..misc import resize_thread_pool
+from ..parallel import local_bands
+
+
+class _BandWorkerImpl:
+    def __init__(self, nthreads):
+        resize_thread_pool(nthreads)
+        self._nthreads = nthreads
+        self._hess = None
+        self._parts = None
+        self._hess_parts = None
+        self._dirty = None
+        self._resid = None
+
+    # --- band loading ---
+    def set_band(self, dirty, parts, hess_parts=None):
+        """In-memory equivalent of ``load_band``: ``dirty (corr,nx,ny)``, gridding partitions
+        (UVW/WEIGHT/MASK/FREQ/BEAM + l0/m0) and optionally the Hessian partitions."""
+        self._dirty = None if dirty is None else np.asarray(dirty)
+        self._parts = list(parts) if parts is not None else None
+        self._hess_parts = hess_parts
+        if self._resid is not None:
+            self._resid.close()
+            self._resid = None
+
+    def load_band(self, store_url, node_name):
+        """Read this band's inputs from the ``.dt`` store (band_worker.py:61-106).  Needs the
+        reference's I/O stack (xarray + zarr); the arrays then stay pinned on this worker's GPU."""
+        import gc
+
+        try:
+            import xarray as xr
+        except ImportError as e:  # pragma: no cover - I/O stack is not part of this package
+            raise ImportError("load_band needs xarray/zarr (the reference's storage layer); "
+                              "use set_band() with in-memory arrays instead") from e
+        try:
+            band = xr.open_datatree(store_url, engine="zarr", chunks=None)[node_name]
+            dirty = band.ds.DIRTY.values
+            parts, hess_parts = [], []
+            for cname in sorted(band.children):
+                child = band[cname].ds
+                pds = child[["UVW", "WEIGHT", "MASK", "FREQ", "BEAM"]].load()
+                pds.attrs.update(child.attrs)
+                hess_parts.append({"psfhat": np.abs(child.PSFHAT.values), "beam": pds.BEAM.values,
+                                   "wsum": np.asarray(child.attrs["wsum"])})
+                parts.append(pds)
+            self.set_band(dirty, parts, hess_parts)
+        finally:
+            gc.collect()
+
+    # --- Hessian role ---
+    def init_hess(self, partitions, nx, ny, nx_psf, ny_psf, eta, wsum):
+        from .hessian import HessianTree
+
+        if partitions is None:
+            partitions = self._hess_parts
+            if partitions is None:
+                raise RuntimeError("no partitions passed and none loaded; call load_band first")
+        self._hess = HessianTree(partitions, nx, ny, nx_psf, ny_psf, eta=eta, nthreads=self._nthreads, wsum=wsum)
+
+    def hess_dot(self, x):
+        return self._hess.dot(x)
+
+    def cg(self, rhs, x0, tol, maxit, minit, verbosity):
+        # whole solve on the device; x0 is copied (Ray-style read-only inputs are never written)
+        return self._hess.cg(rhs, x0=x0, tol=tol, maxit=maxit, minit=minit)
+
+    # --- exact residual role ---
+    def residual(self, model, cell_rad, epsilon, do_wgridding, double_accum):
+        from .gridder import PartitionResidual
+
+        ncorr, nx, ny = self._dirty.shape
+        key = (cell_rad, epsilon, bool(do_wgridding))
+        if self._resid is None or self._resid_key != key:
+            if self._resid is not None:
+                self._resid.close()
+            self._resid = PartitionResidual(self._parts, nx, ny, cell_rad, epsilon=epsilon, do_wgridding=do_wgridding)
+            self._resid_key = key
+        if not np.any(model):
+            return self._dirty - np.zeros_like(self._dirty)
+        return self._dirty - self._resid.convim(model)
+
+    # --- wavelet role: next component ---
+    def init_psi(self, nx, ny, bases, nlevel):
+        raise NotImplementedError("the SARA wavelet dictionary is not part of the measurement-operator path")
+
+    # --- telemetry ---
+    def get_mem(self):
+        import ctypes as ct
+        import os
+
+        free, total = ct.c_size_t(0), ct.c_size_t(0)
+        _lib.check(_lib.lib().pfbhip_mem_info(ct.byref(free), ct.byref(total)))
+        return {"pid": os.getpid(), "hbm_used_gb": (total.value - free.value) / 2**30, "hbm_total_gb": total.value / 2**30}
+
+
+class BandWorkerPool:
+    """nband band workers plus cube-level dispatch (band_worker.py:209-319).
+
+    Args:
+        nband: number of imaging bands.
+        nthreads: kept for signature compatibility.
+        comm: optional ``parallel.BandComm``; bands are then sharded ``b % world_size``.
+    """
+
+    def __init__(self, nband, nthreads=1, comm=None, worker_cls=_BandWorkerImpl):
+        self.nband = nband
+        self.nthreads_per_band = max(1, nthreads)
+        self.comm = comm
+        rank = 0 if comm is None else comm.rank
+        world = 1 if comm is None else comm.world_size
+        self.local = local_bands(nband, rank, world)
+        self.workers = {b: worker_cls(self.nthreads_per_band) for b in self.local}
+        self.actors = None  # no Ray
+
+    def _map(self, method, per_band_args):
+        """Run ``method(*args)`` on every LOCAL band worker; returns {band: result}."""
+        return {b: getattr(self.workers[b], method)(*per_band_args[b]) for b in self.local}
+
+    def _exchange(self, cube):
+        """Every band of ``cube`` was filled by exactly one rank (zeros elsewhere): sum = gather."""
+        if self.comm is None or self.comm.world_size == 1:
+            return cube
+        return self.comm.allreduce_sum(cube).reshape(cube.shape)
+
+    # --- band loading ---
+    def load_bands(self, store_url, node_names):
+        if len(node_names) != self.nband:
+            raise ValueError(f"got {len(node_names)} band nodes for {self.nband} workers")
+        self._map("load_band", [(store_url, node_names[b]) for b in range(self.nband)])
+
+    def set_bands(self, dirty_per_band, parts_per_band, hess_parts_per_band=None):
+        for b in self.local:
+            self.workers[b].set_band(dirty_per_band[b], parts_per_band[b],
+                                     None if hess_parts_per_band is None else hess_parts_per_band[b])
+
+    # --- Hessian role ---
+    def init_hess(self, partitions_per_band, nx, ny, nx_psf, ny_psf, etas, wsums):
+        self._map("init_hess", [(None if partitions_per_band is None else partitions_per_band[b], nx, ny, nx_psf,
+                                 ny_psf, etas[b], wsums[b]) for b in range(self.nband)])
+
+    def hess_dot(self, x):
+        out = np.zeros_like(x, dtype=np.float64)
+        for b, res in self._map("hess_dot", [(x[b],) for b in range(self.nband)]).items():
+            out[b] = res[0]
+        return self._exchange(out)
+
+    def hess_cg(self, rhs, x0, tol, maxit, minit, verbosity):
+        out = np.zeros_like(rhs, dtype=np.float64)
+        args = [(rhs[b], None if x0 is None else x0[b], tol, maxit, minit, verbosity) for b in range(self.nband)]
+        for b, res in self._map("cg", args).items():
+            out[b] = res
+        return self._exchange(out)
+
+    # --- Psi role ---
+    def init_psi(self, nx, ny, bases, nlevel):
+        raise NotImplementedError("the SARA wavelet dictionary is not part of the measurement-operator path")
+
+    # --- exact residual role ---
+    def residual(self, model, cell_rad, epsilon=1e-7, do_wgridding=True, double_accum=True):
+        """Exact per-band residual for a ``(nband, corr, nx, ny)`` model cube."""
+        args = [(model[b], cell_rad, epsilon, do_wgridding, double_accum) for b in range(self.nband)]
+        res = self._map("residual", args)
+        out = np.zeros(model.shape, dtype=np.float64)
+        for b, r in res.items():
+            out[b] = r
+        return self._exchange(out)
+
+    def residual_mfs(self, model, cell_rad, wsum, epsilon=1e-7, do_wgridding=True, double_accum=True, root=0):
+        """``sum_b residual_b / wsum`` on the root rank (None elsewhere): the band reduce of
+        core/deconv.py:320-321 as ONE sum-to-root instead of a gather + host sum."""
+        args = [(model[b], cell_rad, epsilon, do_wgridding, double_accum) for b in range(self.nband)]
+        res = self._map("residual", args)
+        local = np.zeros(model.shape[1:], dtype=np.float64)
+        for r in res.values():
+            local += r
+        total = local if self.comm is None else self.comm.reduce_sum(local, root=root)
+        return None if total is None else total.reshape(local.shape) / wsum
+
+    # --- telemetry ---
+    def get_mem(self):
+        return list(self._map("get_mem", [()] * self.nband).values())

@@ -1,0 +1,153 @@
+"""Band-parallel runtime: one process per GPU, bands sharded round-robin, RCCL band reduce.
+
+Imaging bands are the reference's parallel axis (one Ray actor per band,
+/root/reference/src/pfb_imaging/operators/band_worker.py:217-237; driver-side sums
+``residual_mfs = sum_b residual_b / wsum``, core/deconv.py:320-321, core/grid.py:430-446).
+Here band ``b`` lives on rank ``b % world_size`` for the whole run; gridding, degridding,
+Hessian applies and CG need no communication; only the summed dirty/residual image crosses
+xGMI, as one large ``reduce(sum)`` to the root rank.
+
+Two transports sit behind the same methods:
+  * ``rccl``  -- ``pfbhip_comm_*`` (RCCL over xGMI) on device buffers: the product path on GPUs;
+  * ``gloo``  -- ``torch.distributed`` on host tensors: only for CPU tests of the sharding /
+                 reduce logic (there is no GPU in the authoring container).
+``torch.distributed`` is also the launcher-side rendezvous (torchrun env) that carries RCCL's
+unique id from rank 0 to the other ranks; it is plumbing, not compute.
+"""
+
+import ctypes as ct
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import DeviceArray, check, cint, i64, lib, ptr
+
+
+def band_owner(band, world_size):
+    return band % world_size
+
+
+def local_bands(nband, rank, world_size):
+    return [b for b in range(nband) if band_owner(b, world_size) == rank]
+
+
+class BandComm:
+    def __init__(self, rank=0, world_size=1, local_rank=0, transport=None):
+        self.rank, self.world_size, self.local_rank = rank, world_size, local_rank
+        self.transport = transport
+        self._h = None
+        self._dist = None
+
+    # -- construction ------------------------------------------------------
+    @classmethod
+    def from_env(cls, transport=None, set_device=True):
+        """Build from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
+        rank = int(os.environ.get("RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if transport is None:
+            transport = "rccl" if _lib.device_count() > 0 else "gloo"
+        self = cls(rank, world, local_rank, transport)
+        if transport == "rccl" and set_device:
+            ndev = _lib.device_count()
+            check(lib().pfbhip_set_device(cint(local_rank % max(ndev, 1))))
+        if world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if not dist.is_initialized():
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            self._dist = dist
+        if transport == "rccl":
+            uid = np.zeros(_lib.UNIQUE_ID_BYTES, dtype=np.uint8)
+            if rank == 0:
+                check(lib().pfbhip_comm_unique_id(ptr(uid)))
+            if world > 1:
+                import torch
+
+                t = torch.from_numpy(uid)
+                self._dist.broadcast(t, src=0)
+            h = ct.c_void_p()
+            check(lib().pfbhip_comm_create(ptr(uid), cint(world), cint(rank), ct.byref(h)))
+            self._h = h
+        return self
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().pfbhip_comm_destroy(self._h)
+            self._h = None
+
+    # -- collectives ----------------------------------------------------------
+    def barrier(self):
+        if self.world_size == 1:
+            return
+        if self.transport == "rccl":
+            check(lib().pfbhip_comm_barrier(self._h))
+        else:
+            self._dist.barrier()
+
+    def reduce_sum_dev(self, send, recv, root=0):
+        """RCCL sum-to-root of device buffers (the product's band reduce)."""
+        assert self.transport == "rccl"
+        n = int(np.prod(send.shape, dtype=np.int64))
+        check(lib().pfbhip_comm_reduce_sum(self._h, send.ptr, None if recv is None else recv.ptr, i64(n), cint(root)))
+
+    def allreduce_sum_dev(self, send, recv):
+        assert self.transport == "rccl"
+        n = int(np.prod(send.shape, dtype=np.int64))
+        check(lib().pfbhip_comm_allreduce_sum(self._h, send.ptr, recv.ptr, i64(n)))
+
+    def reduce_sum(self, arr, root=0):
+        """Sum a float64 host array over ranks; the root gets the total, others get None."""
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.world_size == 1:
+            return arr
+        if self.transport == "rccl":
+            d = DeviceArray.from_host(arr)
+            r = DeviceArray(arr.shape, np.float64) if self.rank == root else None
+            self.reduce_sum_dev(d, r, root)
+            out = r.download() if r is not None else None
+            d.free()
+            if r is not None:
+                r.free()
+            return out
+        import torch
+
+        t = torch.from_numpy(arr.copy())
+        self._dist.reduce(t, dst=root)
+        return t.numpy() if self.rank == root else None
+
+    def allreduce_sum(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.world_size == 1:
+            return arr
+        if self.transport == "rccl":
+            d = DeviceArray.from_host(arr)
+            self.allreduce_sum_dev(d, d)
+            out = d.download()
+            d.free()
+            return out
+        import torch
+
+        t = torch.from_numpy(arr.copy())
+        self._dist.all_reduce(t)
+        return t.numpy()
+
+    def max_over_ranks(self, value):
+        if self.world_size == 1:
+            return float(value)
+        import torch
+
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def sum_over_ranks(self, value):
+        if self.world_size == 1:
+            return float(value)
+        import torch
+
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t)
+        return float(t[0])

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors under tests/golden/.
+
+The reference stores no golden vectors for this path (its tests are analytic, the test data
+is a MeasurementSet downloaded at run time) and its arithmetic lives in ducc0, which cannot
+be imported here.  These fixtures are therefore produced by this repository's own exact
+direct-DFT oracle (oracle/dft.py) on the *inputs* the reference's tests construct; nothing is
+imported from /root/reference.
+
+  conventions_two_sources.npz   inputs + expected visibilities of test_wgridder_conventions
+                                (/root/reference/tests/test_hessian_approx.py:128-185: seed 42,
+                                100 antennas, 2 freqs 700-2000 MHz, npix 1024, 0.5" cells, two unit
+                                point sources, five centre offsets, divide_by_n=True)
+  synth_partition.npz           _synth_partition(nrow=200, seed=0) of
+                                /root/reference/tests/test_imager_pass2.py:10-29 with DFT dirty (16^2)
+                                and PSF (32^2) under wgridder_conventions(0, 0)
+  uv2xy.npz                     the uv -> cell index vectors of test_uv2xy
+                                (/root/reference/tests/test_weighting.py:121-137)
+  wstack_small.npz              a 48^2 wide-field case (w-planes > kernel support) with DFT dirty,
+                                DFT model visibilities and the DFT exact Hessian of a random image
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+
+import itertools
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import dft, synth  # noqa: E402
+
+
+def conventions():
+    np.random.seed(42)
+    npix, num_ants, num_freqs = 1024, 100, 2
+    pixsize = 0.5 * np.pi / 180 / 3600.0
+    a1, a2 = np.asarray(list(itertools.combinations(range(num_ants), 2))).T
+    ant = 10e3 * np.random.normal(size=(num_ants, 3))
+    ant[:, 2] *= 0.001
+    uvw = ant[a1] - ant[a2]
+    freqs = np.linspace(700e6, 2000e6, num_freqs)
+    offsets = np.array([(0.0, 0.0), (0.1, -0.17), (0.2, 0.5), (-0.1, 0.2), (-0.15, -0.2)])
+    dirty = np.zeros((npix, npix))
+    dirty[npix // 2, npix // 2] = 1.0
+    dirty[npix // 4, npix // 4] = 1.0
+    vis = []
+    for l0, m0 in offsets:
+        # wgridder_conventions(l0, m0) = (False, True, False, -l0, -m0)
+        vis.append(dft.dft_dirty2vis(uvw, freqs, dirty, pixsize, pixsize, -l0, -m0, False, True, False, True, True))
+    np.savez_compressed(os.path.join(HERE, "conventions_two_sources.npz"), uvw=uvw, freq=freqs, npix=npix,
+                        pixsize=pixsize, offsets=offsets, vis=np.array(vis))
+
+
+def synth_partition():
+    rng = np.random.default_rng(0)
+    nrow = 200
+    uvw = rng.standard_normal((nrow, 3)) * 100.0
+    freq = np.array([1.0e9])
+    vis = rng.standard_normal((1, nrow, 1)) + 1j * rng.standard_normal((1, nrow, 1))
+    wgt = np.abs(rng.standard_normal((1, nrow, 1))) + 0.1
+    mask = np.ones((nrow, 1), dtype=np.uint8)
+    cell = 1.0e-6
+    dirty = dft.dft_vis2dirty(uvw, freq, vis[0], wgt[0], mask, 16, 16, cell, cell, 0.0, 0.0, False, True, False, True,
+                              False)
+    psf = dft.dft_vis2dirty(uvw, freq, np.ones((nrow, 1), complex), wgt[0], mask, 32, 32, cell, cell, 0.0, 0.0, False,
+                            True, False, True, False)
+    np.savez_compressed(os.path.join(HERE, "synth_partition.npz"), uvw=uvw, freq=freq, vis=vis, wgt=wgt, mask=mask,
+                        cell=cell, dirty=dirty, psf=psf, wsum=(wgt[0] * mask).sum())
+
+
+def uv2xy():
+    out = {}
+    for nx in (128, 1034, 44, 10000):
+        for cellx in (1.0, 0.01, 100, 1e-5):
+            np.random.seed(42)
+            ucell = 1.0 / (nx * cellx)
+            u = (-(nx // 2) + np.arange(nx)) * ucell
+            out[f"u_{nx}_{cellx}"] = u + np.random.random(nx) * ucell
+    np.savez_compressed(os.path.join(HERE, "uv2xy.npz"), **out)
+
+
+def wstack_small():
+    c = synth.make_case(nrow=1500, nchan=2, npix=48, zscale=0.3, seed=11)
+    cell = c["cell"] * 40.0
+    args = (48, 48, cell, cell, 0.004, -0.003, False, True, False, True, False)
+    dirty = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], c["mask"], *args)
+    mvis = dft.dft_dirty2vis(c["uvw"], c["freq"], c["x"], cell, cell, 0.004, -0.003, False, True, False, True, False)
+    mvis[c["mask"] == 0] = 0
+    hess = dft.dft_vis2dirty(c["uvw"], c["freq"], mvis, c["wgt"], c["mask"], *args)
+    np.savez_compressed(os.path.join(HERE, "wstack_small.npz"), uvw=c["uvw"], freq=c["freq"], vis=c["vis"],
+                        wgt=c["wgt"], mask=c["mask"], cell=cell, x=c["x"], center=np.array([0.004, -0.003]),
+                        dirty=dirty, mvis=mvis, hess=hess)
+
+
+if __name__ == "__main__":
+    conventions()
+    synth_partition()
+    uv2xy()
+    wstack_small()
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
