@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: exact Hessian apply (degrid + grid with w-stacking and 2-D FFTs) on
+BASELINE.json's configs[1]: 1 band, 1e7 synthetic visibilities, 8192^2 image, one band per GPU.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one Hessian apply  out = R^H W R x  on every rank's band (inputs resident in HBM:
+tile-sorted visibilities, weights, image) followed, when N > 1, by the RCCL sum-to-root of the
+per-band result images (the band reduce of core/deconv.py:320-321).  Rank 0 prints ONE JSON line.
+
+value      = whole-job visibility throughput: N * 2 * nactive / t_step (a Hessian apply touches
+             every unmasked visibility twice: degrid + grid), in Mvis/s.
+roofline   = the dominant device stage of the apply, timed live with HIP events on the handle's
+             stream (pfbhip_gridder_profile): achieved = algorithmic bytes per launch / average
+             launch duration (SURVEY.md section 8(d) accounting, restated in DESIGN.md).
+cpu_baseline = the oracle's CPU restatement (kind "port"; ducc0 itself is not installable) timed
+             on this box's host cores on a bounded sample (a few w-planes of the same workload).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(info, nx, ny, nrow, nactive):
+    """compulsory traffic of one Hessian apply and of one launch per stage."""
+    Sc, Sr = 16, 8
+    G = info["nu"] * info["nv"] * Sc
+    I = nx * ny * Sr
+    P = info["nplanes"]
+    b_vis = nactive * (2 * Sc + Sr + 2) + 2 * nrow * 24
+    b_grid = P * (12 * G + 3 * I)
+    per_launch = {
+        # one launch = one w-plane
+        "fft": 4 * G,                      # 1 read + 1 write per axis
+        "grid": G + nactive * (Sc + 24),   # plane written once + sorted vis value and (pu,pv,pw) record read
+        "degrid": G + nactive * (Sc + 24),  # plane read once + record read, vis accumulator updated
+        "pad_screen": G + I,               # image read, plane written
+        "crop_screen": G + 2 * I,          # plane read, image read-modify-write
+    }
+    return b_vis + b_grid, per_launch
+
+
+def cpu_baseline(case, ginfo, oracle_params, nplanes_sample=2):
+    """Oracle (CPU port) timing of `nplanes_sample` w-planes of the same Hessian apply."""
+    from oracle import _lib as olib
+    from oracle import wgridder as owg
+
+    c = case
+    t0 = time.time()
+    plan = owg.Plan(c["uvw"], c["freq"], c["mask"], c["nx"], c["ny"], c["cell"], c["cell"], 0.0, 0.0, 1e-7, False,
+                    True, False, True, False, params=oracle_params)
+    t_plan = time.time() - t0
+    P = plan.p.nplanes
+    planes = sorted(set(np.linspace(0, P - 1, nplanes_sample).round().astype(int).tolist()))
+    swgt = np.ascontiguousarray(c["wgt"], dtype=np.float64).reshape(-1)
+    acc_img = np.zeros((c["nx"], c["ny"]))
+    sacc = np.zeros(plan.nrow * plan.nchan, dtype=np.complex128)
+    dc = np.ascontiguousarray(c["x"])
+    t0 = time.time()
+    for p in planes:
+        plan.plane_round_trip(dc, swgt, p, acc_img, sacc)
+    t = time.time() - t0
+    t_apply = t / len(planes) * P
+    nactive = int(plan.active.sum())
+    return {
+        "value": 2 * nactive / t_apply / 1e6,
+        "unit": "Mvis/s",
+        "cores": int(olib.lib().pfbo_num_threads()),
+        "kind": "port",
+        "sample": f"{len(planes)} of {P} w-planes of the same apply (all {nactive} vis, {c['nx']}^2 image, "
+                  f"grid {plan.p.nu}x{plan.p.nv}); {t:.1f} s measured, scaled by {P}/{len(planes)}",
+        "sec_per_apply_est": t_apply,
+        "plan_sec": t_plan,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C2", help="C2 (headline), C1, C4 or 'nrow,nchan,npix'")
+    ap.add_argument("--epsilon", type=float, default=1e-7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-planes", type=int, default=2)
+    args = ap.parse_args()
+
+    from pfb_imaging_amd import _lib
+    from pfb_imaging_amd._lib import DeviceArray
+    from pfb_imaging_amd.parallel import BandComm
+    from pfb_imaging_amd.utils import synth
+    from pfb_imaging_amd.wgridder import Gridder
+
+    _lib.require_gpu()  # fail loudly: no CPU path
+    comm = BandComm.from_env()
+    rank, world = comm.rank, comm.world_size
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    # ---- this rank's band -------------------------------------------------
+    if args.config in synth.CONFIGS:
+        case = synth.make_config(args.config, band=rank)
+        wl = f"{args.config}: 1 band/GPU, {synth.CONFIGS[args.config][0]}x{synth.CONFIGS[args.config][1]} vis, " \
+             f"{synth.CONFIGS[args.config][2]}^2 image, exact Hessian apply (degrid+FFT+grid), double precision"
+    else:
+        nrow, nchan, npix = (int(v) for v in args.config.split(","))
+        case = synth.make_case(nrow, nchan, npix, seed=rank)
+        wl = f"custom {nrow}x{nchan} vis, {npix}^2 image"
+    nx, ny = case["nx"], case["ny"]
+    t0 = time.time()
+    g = Gridder(case["uvw"], case["freq"], case["mask"], npix_x=nx, npix_y=ny, pixsize_x=case["cell"],
+                pixsize_y=case["cell"], center_x=0.0, center_y=0.0, epsilon=args.epsilon, flip_u=False, flip_v=True,
+                flip_w=False, do_wgridding=True, divide_by_n=False, sigma_min=1.1, sigma_max=3.0)
+    g.set_weights(case["wgt"])
+    t_plan = time.time() - t0
+    info = g.info
+    wsum = float(case["wgt"][case["mask"] != 0].sum())
+    x_dev = DeviceArray.from_host(case["x"])
+    out_dev = DeviceArray((nx, ny), np.float64)
+    red_dev = DeviceArray((nx, ny), np.float64) if (world > 1 and rank == 0) else None
+
+    def step():
+        g.hessian_dev(x_dev, out_dev, eta=0.0, wsum=wsum)
+        if world > 1:
+            comm.reduce_sum_dev(out_dev, red_dev, root=0)
+
+    for _ in range(args.warmup):
+        step()
+    comm.barrier()
+    _lib.check(_lib.lib().pfbhip_synchronize())
+    g.profile(True)
+    g.profile_get(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _lib.check(_lib.lib().pfbhip_synchronize())
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    stages = g.profile_get(reset=True)
+    g.profile(False)
+    elapsed = comm.max_over_ranks(elapsed)
+    total_active = comm.sum_over_ranks(g.nactive)
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        b_apply, per_launch = algorithmic_bytes(info, nx, ny, case["uvw"].shape[0], g.nactive)
+        dom = max((s for s in stages if s in per_launch), key=lambda s: stages[s][0])
+        dom_ms, dom_calls = stages[dom]
+        avg_ms = dom_ms / max(dom_calls, 1)
+        achieved = per_launch[dom] / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom)
+            except Exception:
+                traffic = None
+        stage_ms = {s: round(v[0] / args.steps, 3) for s, v in stages.items()}
+        out = {
+            "metric": "Mvis/s gridded+degridded in exact Hessian applies (8192^2 grid, 1e7 vis/band)",
+            "value": total_active * 2 / (elapsed / args.steps) / 1e6,
+            "unit": "Mvis/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "hessian_applies_per_s": world / (elapsed / args.steps),
+            "config": {
+                "workload": wl, "bands": world, "vis_per_band": int(case["uvw"].shape[0] * case["freq"].size),
+                "active_vis_per_band": int(g.nactive), "image": [nx, ny], "epsilon": args.epsilon,
+                "grid": [info["nu"], info["nv"]], "w_planes": info["nplanes"], "kernel_support": info["W"],
+                "sigma": info["sigma"], "parallelism": f"band-per-gpu x{world}" + (" + RCCL reduce" if world > 1 else ""),
+                "plan_seconds": round(t_plan, 2),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "alg_bytes_per_launch": per_launch[dom], "avg_launch_ms": avg_ms, "launches": dom_calls,
+                "apply_alg_bytes": b_apply,
+                "apply_frac": b_apply / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                "stage_ms_per_step": stage_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(case, info, g.oracle_params(), args.cpu_planes)
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "Mvis/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(out), flush=True)
+    comm.barrier()
+    g.close()
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,8 +78,9 @@ typedef struct pfbhip_gridder_params {
     int32_t do_wgridding;
     int32_t divide_by_n;
     int32_t verbosity;
-    /* 0 / 0.0 = automatic.  Tests pin the kernel row with these. */
+    /* 0 / 0.0 = automatic.  Tests pin the kernel row / w-plane scheme with these. */
     int32_t force_W;
+    int32_t force_wmode; /* 0 auto, 1 ES-kernel w-planes, 2 polynomial (Chebyshev-node) w-planes */
     double force_sigma;
 } pfbhip_gridder_params;
 
@@ -92,7 +93,14 @@ typedef struct pfbhip_gridder_info {
     double beta, sigma;    /* ES kernel exp(beta (sqrt(1-x^2) - 1)), design oversampling */
     double wmin, dw;       /* plane p sits at w = wmin + p dw (wavelengths)   */
     double nshift, lshift, mshift;
-    double kernel_eps;     /* tabulated 1-D L2 error of the chosen row        */
+    double kernel_eps;     /* tabulated 1-D image-edge error of the chosen row  */
+    /* w-plane scheme.  wmode 0: W-wide ES kernel over equispaced planes wmin + p dw (classic
+     * w-stacking; each visibility touches W planes).  wmode 1: the w range [wcenter - whalf,
+     * wcenter + whalf] is interpolated by a degree-(nplanes-1) polynomial through Chebyshev
+     * nodes (each visibility touches all planes with Lagrange weights; no w-correction in the
+     * image).  The cheaper admissible scheme is chosen per plan. */
+    int32_t wmode, reserved;
+    double wcenter, whalf;
     size_t device_bytes;   /* device memory held by the handle                */
 } pfbhip_gridder_info;
 
@@ -101,6 +109,9 @@ int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw
                           pfbhip_gridder **out);
 int pfbhip_gridder_destroy(pfbhip_gridder *g);
 int pfbhip_gridder_get_info(const pfbhip_gridder *g, pfbhip_gridder_info *info);
+
+/* w (wavelengths) of each of the nplanes planes. */
+int pfbhip_gridder_get_planes(const pfbhip_gridder *g, double *w_host /* [nplanes] */);
 
 /* The bit-exact uv-cell / tile / plane map, for parity tests: per visibility
  * (row-major (nrow,nchan)) first-tap indices iu0, iv0, first plane p0, the

@@ -17,5 +17,4 @@ Modules
     wgridder   ES-kernel w-stacking restatement (C scatter/gather + scipy FFT)
     fftconv    numpy restatement of psf_convolve_* / HessPSF / HessianTree
     weighting  uv-cell index map, counts, Briggs weights
-    synth      synthetic inputs of BASELINE.md section 2
 """

@@ -68,7 +68,7 @@ static inline void cexp2pi(double cycles, double *c, double *s)
 /*
  * dirty[k] = sum_{r,c} mask*wgt * Re( vis * exp(+2 pi i fc (u l + v m - w (n-1))) ) [/ n]
  * evaluated at the npixsel pixels (ix[k], iy[k]).
- *   l = lshift + (ix - nx/2) * px ; m = mshift + (iy - ny/2) * py
+ *   l = lshift + (ix - nx/2) * px ; m = mshift + (iy - ny/2) * py   (integer nx/2: pixel nx/2 is the phase centre)
  *   (u, v, w) already carry the flip signs su, sv, sw.
  * Formula: /root/reference/tests/test_hessian_approx.py:44-67 (adjoint of it).
  */
@@ -81,8 +81,8 @@ void pfbo_dft_vis2dirty(int64_t nrow, int64_t nchan, const double *uvw, const do
 {
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t k = 0; k < npixsel; ++k) {
-        double l = lshift + ((double)ix[k] - 0.5 * (double)nx) * px;
-        double m = mshift + ((double)iy[k] - 0.5 * (double)ny) * py;
+        double l = lshift + (double)(ix[k] - nx / 2) * px;
+        double m = mshift + (double)(iy[k] - ny / 2) * py;
         double nm1 = do_w ? nm1_of(l, m) : 0.0;
         double acc = 0.0, comp = 0.0;
         for (int64_t r = 0; r < nrow; ++r) {
@@ -124,8 +124,8 @@ void pfbo_dft_dirty2vis(int64_t nsel, const int64_t *row, const int64_t *chan, c
     for (int64_t i = 0; i < npix; ++i) {
         if (dirty[i] == 0.0) continue;
         int64_t a = i / ny, b = i % ny;
-        double l = lshift + ((double)a - 0.5 * (double)nx) * px;
-        double m = mshift + ((double)b - 0.5 * (double)ny) * py;
+        double l = lshift + (double)(a - nx / 2) * px;
+        double m = mshift + (double)(b - ny / 2) * py;
         double nm1 = do_w ? nm1_of(l, m) : 0.0;
         double val = dirty[i];
         if (divide_by_n) val /= (nm1 + 1.0);
@@ -160,6 +160,19 @@ static inline double es_kernel(double x, double beta)
     return (t >= 0.0) ? exp(beta * (sqrt(t) - 1.0)) : 0.0;
 }
 
+/* Kernel value of tap `a` for the visibility whose first tap is i0 at grid coordinate p:
+ * either the exact ES kernel (ktab == NULL) or its piecewise polynomial of degree D in
+ * z = 2 f - 1, f = p + 1 - W/2 - i0 in [0,1)  (the form the product's kernels evaluate). */
+static inline double tap_kernel(int a, int i0, double p, int W, double beta, const double *ktab, int D)
+{
+    if (!ktab) return es_kernel(((double)(i0 + a) - p) * (2.0 / (double)W), beta);
+    double z = 2.0 * ((p + (1.0 - 0.5 * (double)W)) - (double)i0) - 1.0;
+    const double *c = ktab + (size_t)a * (size_t)(D + 1);
+    double v = c[D];
+    for (int k = D - 1; k >= 0; --k) v = fma(v, z, c[k]);
+    return v;
+}
+
 /*
  * Per-visibility position map.  THE bit-exact contract shared with the HIP
  * kernels (pfb-imaging_amd/csrc/vismap.hpp): every statement below is one
@@ -171,6 +184,9 @@ static inline double es_kernel(double x, double beta)
  *   xu      = u * px ; fu = xu - floor(xu) ; pu = fu * nu
  *   iu0     = (int) floor(pu + (1 - W/2))       first of W taps, may be < 0
  *   pw      = (w - wmin) * xdw ; p0 = (int) floor(pw + (1 - W/2))
+ *             (kernel w-planes: wmin = first plane, xdw = 1/dw;
+ *              polynomial w-planes: wmin = centre of the w range, xdw = 1/half-range, so
+ *              pw = s in [-1,1] is the interpolation abscissa and p0 is unused)
  *
  * active[i] = mask ? mask[i] != 0 : 1
  */
@@ -222,13 +238,12 @@ static inline int64_t wrapi(int64_t i, int64_t n)
  * iv0w/T), `tstart` has ntiles+1 offsets into it.
  */
 void pfbo_grid_plane(int64_t ntiles, const int64_t *tstart, const int64_t *order, const double *pu,
-                     const double *pv, const double *pw, const int32_t *iu0, const int32_t *iv0,
-                     const int32_t *p0, const double *sval /* (n,2) */, int plane, int do_w, int W,
-                     double beta, int64_t nu, int64_t nv, int T, double *grid /* (nu,nv,2) zeroed */)
+                     const double *pv, const int32_t *iu0, const int32_t *iv0, const double *kwv /* per-vis plane weight, 0 = not on this plane */,
+                     const double *sval /* (n,2) */, int W, double beta, const double *ktab /* (W,D+1) or NULL */, int D,
+                     int64_t nu, int64_t nv, int T, double *grid /* (nu,nv,2) zeroed */)
 {
     const int L = T + W - 1;
     const int64_t ntv = (nv + T - 1) / T;
-    const double xs = 2.0 / (double)W;
 #pragma omp parallel
     {
         double *loc = (double *)malloc(sizeof(double) * (size_t)L * L * 2);
@@ -241,17 +256,13 @@ void pfbo_grid_plane(int64_t ntiles, const int64_t *tstart, const int64_t *order
             int any = 0;
             for (int64_t q = tstart[t]; q < tstart[t + 1]; ++q) {
                 int64_t i = order[q];
-                double kw = 1.0;
-                if (do_w) {
-                    int dp = plane - p0[i];
-                    if (dp < 0 || dp >= W) continue;
-                    kw = es_kernel(((double)plane - pw[i]) * xs, beta);
-                }
+                double kw = kwv[i];
+                if (kw == 0.0) continue;
                 any = 1;
                 int64_t lu = wrapi(iu0[i], nu) - bu, lv = wrapi(iv0[i], nv) - bv;
                 for (int a = 0; a < W; ++a) {
-                    ku[a] = es_kernel(((double)(iu0[i] + a) - pu[i]) * xs, beta);
-                    kv[a] = es_kernel(((double)(iv0[i] + a) - pv[i]) * xs, beta);
+                    ku[a] = tap_kernel(a, iu0[i], pu[i], W, beta, ktab, D);
+                    kv[a] = tap_kernel(a, iv0[i], pv[i], W, beta, ktab, D);
                 }
                 double vr = sval[2 * i] * kw, vi = sval[2 * i + 1] * kw;
                 for (int a = 0; a < W; ++a) {
@@ -282,15 +293,14 @@ void pfbo_grid_plane(int64_t ntiles, const int64_t *tstart, const int64_t *order
     }
 }
 
-/* Gather from w-plane `plane` of the (already FFT'd) grid; acc (n,2) += . */
+/* Gather from one (already FFT'd) w-plane; acc (n,2) += kwv * sum_taps. */
 void pfbo_degrid_plane(int64_t ntiles, const int64_t *tstart, const int64_t *order, const double *pu,
-                       const double *pv, const double *pw, const int32_t *iu0, const int32_t *iv0,
-                       const int32_t *p0, int plane, int do_w, int W, double beta, int64_t nu, int64_t nv,
-                       int T, const double *grid, double *acc /* (n,2) */)
+                       const double *pv, const int32_t *iu0, const int32_t *iv0, const double *kwv, int W,
+                       double beta, const double *ktab, int D, int64_t nu, int64_t nv, int T, const double *grid,
+                       double *acc /* (n,2) */)
 {
     const int L = T + W - 1;
     const int64_t ntv = (nv + T - 1) / T;
-    const double xs = 2.0 / (double)W;
 #pragma omp parallel
     {
         double *loc = (double *)malloc(sizeof(double) * (size_t)L * L * 2);
@@ -310,16 +320,12 @@ void pfbo_degrid_plane(int64_t ntiles, const int64_t *tstart, const int64_t *ord
             }
             for (int64_t q = tstart[t]; q < tstart[t + 1]; ++q) {
                 int64_t i = order[q];
-                double kw = 1.0;
-                if (do_w) {
-                    int dp = plane - p0[i];
-                    if (dp < 0 || dp >= W) continue;
-                    kw = es_kernel(((double)plane - pw[i]) * xs, beta);
-                }
+                double kw = kwv[i];
+                if (kw == 0.0) continue;
                 int64_t lu = wrapi(iu0[i], nu) - bu, lv = wrapi(iv0[i], nv) - bv;
                 for (int a = 0; a < W; ++a) {
-                    ku[a] = es_kernel(((double)(iu0[i] + a) - pu[i]) * xs, beta);
-                    kv[a] = es_kernel(((double)(iv0[i] + a) - pv[i]) * xs, beta);
+                    ku[a] = tap_kernel(a, iu0[i], pu[i], W, beta, ktab, D);
+                    kv[a] = tap_kernel(a, iv0[i], pv[i], W, beta, ktab, D);
                 }
                 double sr = 0.0, si = 0.0;
                 for (int a = 0; a < W; ++a) {

@@ -97,6 +97,43 @@ def kernel_ft(v, W, beta):
     return W * out
 
 
+def kernel_poly_degree(W):
+    return min(max(W + 6, 12), 20)
+
+
+def kernel_poly_table(W, beta):
+    """Piecewise-polynomial form of the kernel (the form the gridding kernels evaluate; the
+    reference's gridder does the same with its own kernels): for tap a and sub-cell offset
+    f in [0,1), phi((a + 1 - W/2 - f) 2/W) ~= sum_k c[a,k] z^k, z = 2f - 1, degree
+    clamp(W+6, 12, 20), by Chebyshev interpolation in extended precision."""
+    D = kernel_poly_degree(W)
+    n = D + 1
+    ld = np.longdouble
+    k = np.arange(n, dtype=ld)
+    znodes = np.cos(ld(np.pi) * (k + ld(0.5)) / n)
+    tab = np.zeros((W, n))
+    for a in range(W):
+        f = ld(0.5) * (znodes + 1)
+        x = (ld(a) + 1 - ld(0.5) * W - f) * 2 / W
+        t = np.maximum(1 - x * x, ld(0))
+        fv = np.exp(ld(beta) * (np.sqrt(t) - 1))
+        cc = np.array([2 * np.sum(fv * np.cos(ld(np.pi) * j * (k + ld(0.5)) / n)) / n for j in range(n)], dtype=ld)
+        cc[0] *= ld(0.5)
+        mono = np.zeros(n, dtype=ld)
+        t0 = np.zeros(n, dtype=ld)
+        t1 = np.zeros(n, dtype=ld)
+        t0[0] = 1
+        t1[1] = 1
+        mono += cc[0] * t0 + cc[1] * t1
+        for j in range(2, n):
+            t2 = -t0.copy()
+            t2[1:] += 2 * t1[:-1]
+            mono += cc[j] * t2
+            t0, t1 = t1, t2
+        tab[a] = mono.astype(np.float64)
+    return np.ascontiguousarray(tab)
+
+
 @dataclass
 class GridParams:
     nu: int
@@ -111,14 +148,17 @@ class GridParams:
     lshift: float
     mshift: float
     tile: int = TILE
+    wmode: int = 0        # 0: ES-kernel w-planes (equispaced), 1: polynomial (Chebyshev-node) w-planes
+    wcenter: float = 0.0  # wmode 1: centre of the w range
+    whalf: float = 0.0    # wmode 1: half-width of the w range
 
     def asdict(self):
         return asdict(self)
 
 
 def nm1_image(nx, ny, px, py, lshift, mshift):
-    x = lshift + (np.arange(nx) - 0.5 * nx) * px
-    y = mshift + (np.arange(ny) - 0.5 * ny) * py
+    x = lshift + (np.arange(nx) - nx // 2) * px
+    y = mshift + (np.arange(ny) - ny // 2) * py
     r2 = x[:, None] ** 2 + y[None, :] ** 2
     out = np.empty_like(r2)
     ok = r2 <= 1.0
@@ -161,7 +201,7 @@ def w_range(uvw, freq, mask, flip_w):
 
 
 def choose_params(uvw, freq, mask, nx, ny, px, py, center_x, center_y, epsilon, do_wgridding, flip_u=False,
-                  flip_v=False, flip_w=False, sigma_min=1.1, sigma_max=2.6, force=None):
+                  flip_v=False, flip_w=False, sigma_min=1.1, sigma_max=2.6, force=None, force_wmode=None):
     """Pick (sigma, W, beta), grid size and w-plane layout.
 
     ``force=(sigma, W)`` pins the kernel row (tests use it to mirror the product's
@@ -182,25 +222,59 @@ def choose_params(uvw, freq, mask, nx, ny, px, py, center_x, center_y, epsilon, 
             if not (abs(r["sigma"] - force[0]) < 1e-9 and r["W"] == force[1]):
                 continue
         else:
-            if r["sigma"] < sigma_min - 1e-9 or r["sigma"] > sigma_max + 1e-9 or r["eps"] > eps1:
+            if r["sigma"] < sigma_min - 1e-9 or r["sigma"] > sigma_max + 1e-9 or r["eps_max"] > eps1:
                 continue
         nu, nv = grid_size(nx, r["sigma"]), grid_size(ny, r["sigma"])
-        if do_wgridding and tmax > 0:
-            dw = 0.5 / r["sigma"] / tmax
-            npl = int((whi - wlo) / dw + r["W"])
-        else:
-            dw, npl = 1.0, 1
-        fftcost = 2.5e-9 * npl * nu * nv * np.log2(nu * nv) / 8.0
-        gridcost = 1.2e-9 * nvis * r["W"] ** 2 * (r["W"] if do_wgridding else 1) / 8.0
-        cost = fftcost + gridcost
-        if best is None or cost < best[0]:
-            best = (cost, r, nu, nv, dw, npl)
+        for wmode in ((0, 1) if (do_wgridding and tmax > 0 and force_wmode is None) else
+                      ((force_wmode,) if (do_wgridding and tmax > 0) else (0,))):
+            if do_wgridding and tmax > 0:
+                if wmode == 0:
+                    dw = 0.5 / r["sigma"] / tmax
+                    npl = int((whi - wlo) / dw + r["W"])
+                    touched = r["W"]
+                else:
+                    dw = 1.0
+                    npl = cheb_planes_needed(2.0 * np.pi * 0.5 * (whi - wlo) * tmax, eps1)
+                    if npl is None:
+                        continue
+                    touched = npl
+            else:
+                dw, npl, touched = 1.0, 1, 1
+            fftcost = 2.5e-9 * npl * nu * nv * np.log2(nu * nv) / 8.0
+            gridcost = 1.2e-9 * nvis * r["W"] ** 2 * touched / 8.0
+            cost = fftcost + gridcost
+            if best is None or cost < best[0]:
+                best = (cost, r, nu, nv, dw, npl, wmode)
     if best is None:
         raise ValueError(f"no ES kernel reaches epsilon={epsilon} within sigma in [{sigma_min},{sigma_max}]")
-    _, r, nu, nv, dw, npl = best
-    wmin = 0.5 * (wlo + whi) - 0.5 * (npl - 1) * dw if do_wgridding else 0.0
+    _, r, nu, nv, dw, npl, wmode = best
+    wmin = 0.5 * (wlo + whi) - 0.5 * (npl - 1) * dw if (do_wgridding and wmode == 0) else 0.0
     return GridParams(nu=nu, nv=nv, W=r["W"], beta=r["beta"], sigma=r["sigma"], nplanes=npl, wmin=wmin, dw=dw,
-                      nshift=nshift, lshift=lshift, mshift=mshift)
+                      nshift=nshift, lshift=lshift, mshift=mshift, wmode=wmode, wcenter=0.5 * (wlo + whi),
+                      whalf=0.5 * (whi - wlo))
+
+
+MAX_CHEB_PLANES = 24
+
+
+def cheb_planes_needed(omega, eps):
+    """Smallest K with interpolation error bound omega^K / (2^(K-1) K!) <= eps for exp(i omega s),
+    |s| <= 1, interpolated at K Chebyshev nodes (None if K would exceed MAX_CHEB_PLANES)."""
+    if omega <= 0.0:
+        return 1
+    bound = omega  # K = 1: omega^1 / (2^0 1!)
+    k = 1
+    while bound > eps:
+        k += 1
+        bound *= omega / (2.0 * k)
+        if k > MAX_CHEB_PLANES:
+            return None
+    return k
+
+
+def cheb_nodes(k):
+    """Chebyshev nodes of the first kind on [-1, 1], ascending."""
+    return -np.cos(np.pi * (2.0 * np.arange(k) + 1.0) / (2.0 * k))
 
 
 class Plan:
@@ -209,7 +283,7 @@ class Plan:
 
     def __init__(self, uvw, freq, mask, npix_x, npix_y, pixsize_x, pixsize_y, center_x=0.0, center_y=0.0,
                  epsilon=1e-7, flip_u=False, flip_v=False, flip_w=False, do_wgridding=True, divide_by_n=True,
-                 sigma_min=1.1, sigma_max=2.6, params=None, force=None):
+                 sigma_min=1.1, sigma_max=2.6, params=None, force=None, force_wmode=None, use_poly_kernel=True):
         self.uvw = np.ascontiguousarray(uvw, dtype=np.float64)
         self.freq = np.ascontiguousarray(freq, dtype=np.float64)
         self.mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
@@ -221,7 +295,8 @@ class Plan:
         self.signs = (-1.0 if flip_u else 1.0, -1.0 if flip_v else 1.0, -1.0 if flip_w else 1.0)
         if params is None:
             params = choose_params(self.uvw, self.freq, self.mask, self.nx, self.ny, self.px, self.py, center_x,
-                                   center_y, epsilon, self.do_w, flip_u, flip_v, flip_w, sigma_min, sigma_max, force)
+                                   center_y, epsilon, self.do_w, flip_u, flip_v, flip_w, sigma_min, sigma_max, force,
+                                   force_wmode)
         elif isinstance(params, dict):
             params = GridParams(**params)
         self.p = p = params
@@ -235,10 +310,17 @@ class Plan:
         self.iu0 = np.empty(n, dtype=np.int32)
         self.iv0 = np.empty(n, dtype=np.int32)
         self.p0 = np.empty(n, dtype=np.int32)
-        xdw = 1.0 / p.dw
+        if p.wmode == 0:
+            wmin_map, xdw = p.wmin, 1.0 / p.dw
+            self.wplanes = p.wmin + p.dw * np.arange(p.nplanes)
+            self.nodes = None
+        else:
+            wmin_map, xdw = p.wcenter, (1.0 / p.whalf if p.whalf > 0 else 0.0)
+            self.nodes = cheb_nodes(p.nplanes)
+            self.wplanes = p.wcenter + p.whalf * self.nodes
         lib().pfbo_vismap(i64(self.nrow), i64(self.nchan), ptr(self.uvw), ptr(self.fc), ptr(self.mask),
                           f64(self.signs[0]), f64(self.signs[1]), f64(self.signs[2]), f64(self.px), f64(self.py),
-                          i64(p.nu), i64(p.nv), cint(p.W), cint(int(self.do_w)), f64(p.wmin), f64(xdw), ptr(self.pu),
+                          i64(p.nu), i64(p.nv), cint(p.W), cint(int(self.do_w)), f64(wmin_map), f64(xdw), ptr(self.pu),
                           ptr(self.pv), ptr(self.pw), ptr(self.uvw_l), ptr(self.flip), ptr(self.iu0), ptr(self.iv0),
                           ptr(self.p0))
         # tile sort (tile of the first tap, wrapped)
@@ -256,17 +338,10 @@ class Plan:
         # image-domain quantities
         self.xi = np.mod(np.arange(self.nx) - self.nx // 2, p.nu)
         self.yi = np.mod(np.arange(self.ny) - self.ny // 2, p.nv)
-        cfu = 1.0 / kernel_ft((np.arange(self.nx) - self.nx // 2) / p.nu, p.W, p.beta)
-        cfv = 1.0 / kernel_ft((np.arange(self.ny) - self.ny // 2) / p.nv, p.W, p.beta)
-        corr = cfu[:, None] * cfv[None, :]
-        if self.do_w:
-            self.t = nm1_image(self.nx, self.ny, self.px, self.py, p.lshift, p.mshift) + p.nshift
-            corr = corr / kernel_ft(self.t * p.dw, p.W, p.beta)
-            if self.divide_by_n:
-                corr = corr / (self.t - p.nshift + 1.0)
-        else:
-            self.t = None
-        self.corr = corr
+        self.ktab = kernel_poly_table(p.W, p.beta) if use_poly_kernel else None
+        self.kdeg = kernel_poly_degree(p.W)
+        self._corr = None
+        self.t = nm1_image(self.nx, self.ny, self.px, self.py, p.lshift, p.mshift) + p.nshift if self.do_w else None
         self.shifting = (p.lshift != 0.0) or (p.mshift != 0.0) or (p.nshift != 0.0)
         if self.shifting:
             ph = self.uvw_l[:, 0] * p.lshift + self.uvw_l[:, 1] * p.mshift + self.uvw_l[:, 2] * p.nshift
@@ -276,20 +351,96 @@ class Plan:
             self.phase = None
 
     # -- helpers -------------------------------------------------------
+    @property
+    def corr(self):
+        """Correction image 1/(psi_l psi_m psi_n) [/n], built on first use."""
+        if self._corr is None:
+            p = self.p
+            cfu = 1.0 / kernel_ft((np.arange(self.nx) - self.nx // 2) / p.nu, p.W, p.beta)
+            cfv = 1.0 / kernel_ft((np.arange(self.ny) - self.ny // 2) / p.nv, p.W, p.beta)
+            corr = cfu[:, None] * cfv[None, :]
+            if self.do_w and p.wmode == 0:
+                z = self.t * p.dw
+                zmax = float(np.abs(z).max())
+                if zmax > 0 and z.size > 1_000_000:
+                    # large images: Chebyshev interpolant of 1/psi in (z/zmax)^2 (error < 1e-15)
+                    cheb = np.polynomial.chebyshev.Chebyshev.interpolate(
+                        lambda y: 1.0 / kernel_ft(zmax * np.sqrt(0.5 * (y + 1.0)), p.W, p.beta), 64)
+                    corr = corr * cheb(2.0 * (z / zmax) ** 2 - 1.0)
+                else:
+                    corr = corr / kernel_ft(z, p.W, p.beta)
+            if self.do_w and self.divide_by_n:
+                corr = corr / (self.t - p.nshift + 1.0)
+            self._corr = corr
+        return self._corr
+
+    def plane_round_trip(self, dc, swgt_flat, plane, acc_img, sacc):
+        """One w-plane of an exact-Hessian apply (bench cpu_baseline sample): pad+screen -> FFT ->
+        gather into sacc; then scatter sacc*wgt -> inverse FFT -> crop+screen -> acc_img."""
+        p = self.p
+        grid = np.zeros((p.nu, p.nv), dtype=np.complex128)
+        grid[np.ix_(self.xi, self.yi)] = dc * self._screen(plane, +1.0) if self.do_w else dc
+        grid = sfft.fft2(grid, workers=-1, overwrite_x=True)
+        self._degrid(grid, plane, sacc)
+        sval = sacc * swgt_flat
+        grid = self.grid_plane(sval, plane)
+        img = sfft.ifft2(grid, norm="forward", workers=-1, overwrite_x=True)
+        sub = img[np.ix_(self.xi, self.yi)]
+        if self.do_w:
+            sub *= self._screen(plane, -1.0)
+        acc_img += sub.real
+
+    def plane_weights(self, plane):
+        """Per-visibility weight of w-plane `plane` (0 where the visibility does not touch it)."""
+        p = self.p
+        n = self.pw.size
+        if not self.do_w:
+            return np.ones(n)
+        if p.wmode == 0:
+            dp = plane - self.p0
+            ok = (dp >= 0) & (dp < p.W)
+            if self.ktab is not None:
+                z = 2.0 * ((self.pw + (1.0 - 0.5 * p.W)) - self.p0) - 1.0
+                c = self.ktab[np.clip(dp, 0, p.W - 1)]
+                kw = c[:, self.kdeg].copy()
+                for k in range(self.kdeg - 1, -1, -1):
+                    kw = kw * z + c[:, k]
+            else:
+                x = (plane - self.pw) * (2.0 / p.W)
+                kw = np.exp(p.beta * (np.sqrt(np.maximum(1.0 - x * x, 0.0)) - 1.0))
+            kw[~ok] = 0.0
+            return kw
+        # Lagrange basis polynomial of node `plane` evaluated at s = pw
+        kw = np.ones(n)
+        for m, sm in enumerate(self.nodes):
+            if m != plane:
+                kw *= (self.pw - sm) / (self.nodes[plane] - sm)
+        kw[kw == 0.0] = 1e-300  # keep "touches this plane" semantics (exact zeros are measure-zero)
+        return kw
+
     def _screen(self, plane, sign):
-        w = self.p.wmin + plane * self.p.dw
+        w = self.wplanes[plane]
         ph = w * self.t
         ph -= np.rint(ph)
         return np.exp((sign * 2j * np.pi) * ph)
+
+    def _degrid(self, grid, plane, acc):
+        p = self.p
+        kwv = np.ascontiguousarray(self.plane_weights(plane))
+        lib().pfbo_degrid_plane(i64(self.ntu * self.ntv), ptr(self.tstart), ptr(self.order), ptr(self.pu),
+                                ptr(self.pv), ptr(self.iu0), ptr(self.iv0), ptr(kwv), cint(p.W), f64(p.beta),
+                                ptr(self.ktab), cint(self.kdeg), i64(p.nu), i64(p.nv), cint(p.tile),
+                                ptr(grid.view(np.float64)), ptr(acc.view(np.float64)))
 
     def grid_plane(self, sval, plane):
         """Scatter one w-plane (pre-FFT grid), exposed for intermediate parity tests."""
         p = self.p
         grid = np.zeros((p.nu, p.nv), dtype=np.complex128)
+        kwv = np.ascontiguousarray(self.plane_weights(plane))
         lib().pfbo_grid_plane(i64(self.ntu * self.ntv), ptr(self.tstart), ptr(self.order), ptr(self.pu), ptr(self.pv),
-                              ptr(self.pw), ptr(self.iu0), ptr(self.iv0), ptr(self.p0), ptr(sval.view(np.float64)),
-                              cint(plane), cint(int(self.do_w)), cint(p.W), f64(p.beta), i64(p.nu), i64(p.nv),
-                              cint(p.tile), ptr(grid.view(np.float64)))
+                              ptr(self.iu0), ptr(self.iv0), ptr(kwv), ptr(sval.view(np.float64)), cint(p.W),
+                              f64(p.beta), ptr(self.ktab), cint(self.kdeg), i64(p.nu), i64(p.nv), cint(p.tile),
+                              ptr(grid.view(np.float64)))
         return grid
 
     def prep_vis(self, vis, wgt):
@@ -327,10 +478,7 @@ class Plan:
             grid = np.zeros((p.nu, p.nv), dtype=np.complex128)
             grid[np.ix_(self.xi, self.yi)] = dc * self._screen(plane, +1.0) if self.do_w else dc
             grid = sfft.fft2(grid, workers=-1, overwrite_x=True)
-            lib().pfbo_degrid_plane(i64(self.ntu * self.ntv), ptr(self.tstart), ptr(self.order), ptr(self.pu),
-                                    ptr(self.pv), ptr(self.pw), ptr(self.iu0), ptr(self.iv0), ptr(self.p0),
-                                    cint(plane), cint(int(self.do_w)), cint(p.W), f64(p.beta), i64(p.nu), i64(p.nv),
-                                    cint(p.tile), ptr(grid.view(np.float64)), ptr(acc.view(np.float64)))
+            self._degrid(grid, plane, acc)
         if self.phase is not None:
             acc *= np.conj(self.phase)
         fl = self.flip != 0
@@ -344,11 +492,11 @@ class Plan:
 def vis2dirty(*, uvw, freq, vis, wgt=None, mask=None, npix_x, npix_y, pixsize_x, pixsize_y, center_x=0.0,
               center_y=0.0, epsilon, flip_u=False, flip_v=False, flip_w=False, do_wgridding, divide_by_n=True,
               nthreads=1, sigma_min=1.1, sigma_max=2.6, double_precision_accumulation=False, verbosity=0,
-              dirty=None, params=None, force=None):
+              dirty=None, params=None, force=None, force_wmode=None):
     """Keyword-compatible with ducc0.wgridder.experimental.vis2dirty as called at
     /root/reference/src/pfb_imaging/operators/gridder.py:590-613."""
     plan = Plan(uvw, freq, mask, npix_x, npix_y, pixsize_x, pixsize_y, center_x, center_y, epsilon, flip_u, flip_v,
-                flip_w, do_wgridding, divide_by_n, sigma_min, sigma_max, params, force)
+                flip_w, do_wgridding, divide_by_n, sigma_min, sigma_max, params, force, force_wmode)
     out = plan.vis2dirty(vis, wgt)
     if dirty is not None:
         dirty[...] = out
@@ -358,12 +506,12 @@ def vis2dirty(*, uvw, freq, vis, wgt=None, mask=None, npix_x, npix_y, pixsize_x,
 
 def dirty2vis(*, uvw, freq, dirty, wgt=None, mask=None, pixsize_x, pixsize_y, center_x=0.0, center_y=0.0, epsilon,
               flip_u=False, flip_v=False, flip_w=False, do_wgridding, divide_by_n=True, nthreads=1, sigma_min=1.1,
-              sigma_max=2.6, verbosity=0, vis=None, params=None, force=None):
+              sigma_max=2.6, verbosity=0, vis=None, params=None, force=None, force_wmode=None):
     """Keyword-compatible with ducc0.wgridder.experimental.dirty2vis as called at
     /root/reference/src/pfb_imaging/operators/hessian.py:50-66."""
     nx, ny = dirty.shape
     plan = Plan(uvw, freq, mask, nx, ny, pixsize_x, pixsize_y, center_x, center_y, epsilon, flip_u, flip_v, flip_w,
-                do_wgridding, divide_by_n, sigma_min, sigma_max, params, force)
+                do_wgridding, divide_by_n, sigma_min, sigma_max, params, force, force_wmode)
     out = plan.dirty2vis(dirty, wgt)
     if vis is not None:
         vis[...] = out

@@ -28,7 +28,7 @@ class GridderParams(ct.Structure):
         ("pixsize_x", f64), ("pixsize_y", f64), ("center_x", f64), ("center_y", f64),
         ("epsilon", f64), ("sigma_min", f64), ("sigma_max", f64),
         ("flip_u", i32), ("flip_v", i32), ("flip_w", i32), ("do_wgridding", i32), ("divide_by_n", i32),
-        ("verbosity", i32), ("force_W", i32), ("force_sigma", f64),
+        ("verbosity", i32), ("force_W", i32), ("force_wmode", i32), ("force_sigma", f64),
     ]
 
 
@@ -36,7 +36,8 @@ class GridderInfo(ct.Structure):
     _fields_ = [
         ("nu", i64), ("nv", i64), ("nplanes", i64), ("nactive", i64), ("ntiles", i64), ("nwork", i64),
         ("W", i32), ("tile", i32), ("beta", f64), ("sigma", f64), ("wmin", f64), ("dw", f64),
-        ("nshift", f64), ("lshift", f64), ("mshift", f64), ("kernel_eps", f64), ("device_bytes", ct.c_size_t),
+        ("nshift", f64), ("lshift", f64), ("mshift", f64), ("kernel_eps", f64),
+        ("wmode", i32), ("reserved", i32), ("wcenter", f64), ("whalf", f64), ("device_bytes", ct.c_size_t),
     ]
 
     def asdict(self):
@@ -54,6 +55,7 @@ SYMBOLS = (
     "pfbhip_malloc", "pfbhip_free", "pfbhip_memcpy_h2d", "pfbhip_memcpy_d2h", "pfbhip_memcpy_d2d", "pfbhip_memset",
     "pfbhip_synchronize",
     "pfbhip_gridder_create", "pfbhip_gridder_destroy", "pfbhip_gridder_get_info", "pfbhip_gridder_get_binmap",
+    "pfbhip_gridder_get_planes",
     "pfbhip_gridder_vis2dirty", "pfbhip_gridder_dirty2vis", "pfbhip_gridder_grid_plane",
     "pfbhip_gridder_set_weights", "pfbhip_gridder_hessian", "pfbhip_gridder_hessian_dev",
     "pfbhip_gridder_degrid_dev", "pfbhip_gridder_grid_dev", "pfbhip_gridder_profile", "pfbhip_gridder_profile_get",

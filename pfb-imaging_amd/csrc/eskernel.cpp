@@ -101,6 +101,56 @@ std::vector<double> KernelFT::inverse_cheb(double zmax, double tol) const
     return {};
 }
 
+std::vector<double> kernel_poly_table(int W, double beta, double *max_err)
+{
+    const int D = kernel_poly_degree(W), n = D + 1;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    auto phi = [&](long double x) -> long double {
+        long double t = 1.0L - x * x;
+        return t >= 0.0L ? expl((long double)beta * (sqrtl(t) - 1.0L)) : 0.0L;
+    };
+    std::vector<double> tab(size_t(W) * n);
+    double worst = 0.0;
+    for (int a = 0; a < W; ++a) {
+        auto f_of_z = [&](long double z) {
+            long double f = 0.5L * (z + 1.0L);
+            return phi(((long double)a + 1.0L - 0.5L * W - f) * 2.0L / W);
+        };
+        // Chebyshev coefficients on z in [-1,1]
+        std::vector<long double> fv(n), cc(n);
+        for (int k = 0; k < n; ++k) fv[k] = f_of_z(cosl(pi * (k + 0.5L) / n));
+        for (int j = 0; j < n; ++j) {
+            long double sum = 0.0L;
+            for (int k = 0; k < n; ++k) sum += fv[k] * cosl(pi * j * (k + 0.5L) / n);
+            cc[j] = 2.0L * sum / n;
+        }
+        cc[0] *= 0.5L;
+        // to monomials: T_0 = 1, T_1 = z, T_{j+1} = 2 z T_j - T_{j-1}
+        std::vector<long double> mono(n, 0.0L), t0(n, 0.0L), t1(n, 0.0L), t2(n, 0.0L);
+        t0[0] = 1.0L;
+        t1[1] = 1.0L;
+        for (int k = 0; k < n; ++k) mono[k] += cc[0] * t0[k];
+        if (n > 1)
+            for (int k = 0; k < n; ++k) mono[k] += cc[1] * t1[k];
+        for (int j = 2; j < n; ++j) {
+            for (int k = 0; k < n; ++k) t2[k] = (k > 0 ? 2.0L * t1[k - 1] : 0.0L) - t0[k];
+            for (int k = 0; k < n; ++k) mono[k] += cc[j] * t2[k];
+            t0 = t1;
+            t1 = t2;
+        }
+        for (int k = 0; k < n; ++k) tab[size_t(a) * n + k] = (double)mono[k];
+        // measured error of the double-precision Horner form
+        for (int q = 0; q <= 400; ++q) {
+            double z = -1.0 + 2.0 * q / 400.0;
+            double v = tab[size_t(a) * n + D];
+            for (int k = D - 1; k >= 0; --k) v = v * z + tab[size_t(a) * n + k];
+            worst = std::max(worst, std::fabs(v - (double)f_of_z((long double)z)));
+        }
+    }
+    if (max_err) *max_err = worst;
+    return tab;
+}
+
 int64_t good_size_2357(int64_t n)
 {
     if (n < 1) n = 1;

@@ -10,7 +10,9 @@ namespace pfbhip {
 
 struct KernelRow {
     int W;
-    double sigma, beta, eps;
+    double sigma, beta;
+    double eps;      // 1-D aliasing error, L2 average over the image
+    double eps_max;  // 1-D aliasing error at the image edge (its maximum)
 };
 
 const KernelRow *kernel_table(size_t *n);
@@ -29,5 +31,13 @@ struct KernelFT {
 };
 
 int64_t grid_size(int64_t npix, double sigma);
+
+// Piecewise-polynomial form of the kernel for the device: for tap a (0 <= a < W) and sub-cell
+// offset f in [0,1) (first tap index i0 = floor(p + 1 - W/2), f = p + 1 - W/2 - i0)
+//     phi_a(f) = phi((a + 1 - W/2 - f) * 2 / W)  ~=  sum_k c[a][k] z^k ,  z = 2 f - 1 ,
+// degree D = clamp(W + 6, 12, 20) (Chebyshev interpolation, converted to monomials in long double).
+// Returns c as a row-major (W, D+1) table and the measured max abs error (kernel peak = 1).
+constexpr int kernel_poly_degree(int W) { return W + 6 > 20 ? 20 : (W + 6 < 12 ? 12 : W + 6); }
+std::vector<double> kernel_poly_table(int W, double beta, double *max_err);
 
 }  // namespace pfbhip

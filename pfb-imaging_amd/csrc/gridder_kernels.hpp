@@ -8,14 +8,20 @@
 //             pu[], pv[], pw[] grid coordinates; src[] original index | flip<<31
 //   sval      nactive interleaved complex, tile-sorted         weighted visibilities (grid input / degrid output)
 //   work      (tile, begin, end) chunks of <= CHUNK sorted visibilities of one tile
+//   coef      (W, D+1) monomial coefficients of the kernel's piecewise polynomial (eskernel.hpp)
 //
-// Scatter (k_grid): one workgroup per work item; the (TILE+W-1)^2 footprint of the tile
-// lives in LDS as two planes (re, im); each wavefront reads 64 records coalesced, then walks
-// them with v_readlane broadcasts; lanes < 32 evaluate the 2W one-dimensional kernel values
-// once per visibility, the W^2 taps are spread over the 64 lanes (ds_bpermute broadcast of
-// the 1-D values) and accumulated with LDS f64 atomics; the tile is flushed to HBM with
-// global f64 atomics (halo cells are shared with neighbouring tiles).
-// Gather (k_degrid): the same walk with the tile loaded into LDS and a wavefront reduction.
+// Mapping (both kernels): one workgroup per work item, the (TILE+W-1)^2 footprint of the tile
+// in LDS.  A wavefront handles FOUR visibilities at a time, one per 16-lane DPP row.  Lane b of
+// a row owns footprint column b: it evaluates the v-kernel of tap b and the u-kernel of tap b
+// (two Horner chains on per-lane register coefficients -- no exp/sqrt), then walks the W x W
+// footprint along wrapped diagonals: at step i it holds the u-kernel value of row (b+i) mod 16,
+// obtained by rotating the row's u-values one lane per step with a DPP row_ror (a VALU move,
+// no LDS traffic).  At every step the 16 lanes of a row touch 16 different rows AND columns;
+// with an even LDS row stride that is bank-conflict free.
+//   scatter (k_grid):   LDS f64 atomics (ds_add_f64) into two planes (re, im), then the tile is
+//                       flushed to HBM with global f64 atomics (halo cells are shared by tiles);
+//   gather  (k_degrid): the tile is loaded into LDS as interleaved complex (ds_read_b128 per
+//                       tap), per-lane partial sums, 4-step DPP row reduction.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,26 +36,37 @@ struct WorkItem {
     uint32_t tile, begin, end, pad;
 };
 
+constexpr int MAX_POLY_PLANES = 24;
+
+__host__ __device__ constexpr int kernel_poly_degree_c(int W) { return W + 6 > 20 ? 20 : (W + 6 < 12 ? 12 : W + 6); }
+
 struct PlaneArgs {
     int nu, nv, ntv;
     int do_w;
     int plane;
-    double beta;
-    const double *pu, *pv, *pw;  // tile-sorted records
+    int wmode;    // 0: ES kernel over equispaced planes, 1: Lagrange weights over Chebyshev nodes
+    int nplanes;
+    double coef;                    // wmode 1: prod_{m != plane} 1 / (s_plane - s_m)
+    double nodes[MAX_POLY_PLANES];  // wmode 1: interpolation abscissae s_m in [-1, 1]
+    const double *pu, *pv, *pw;     // tile-sorted records
+    const double *ktab;             // (W, D+1) kernel polynomial coefficients
     const WorkItem *work;
     uint32_t nwork;
 };
 
-__device__ __forceinline__ double es_kernel(double x, double beta)
+// value of lane (l -/+ 1) of the same 16-lane row (direction is irrelevant to the callers: they
+// rotate the tap index alongside the data)
+__device__ __forceinline__ int rot1_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false); }
+__device__ __forceinline__ double rot1_f64(double v)
 {
-    double t = 1.0 - x * x;
-    return t >= 0.0 ? exp(beta * (sqrt(t) - 1.0)) : 0.0;
+    int lo = rot1_i32(__double2loint(v)), hi = rot1_i32(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
-
-__device__ __forceinline__ double readlane_f64(double v, int k)
+template <int N>
+__device__ __forceinline__ double rotn_f64(double v)
 {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
@@ -58,89 +75,123 @@ __device__ __forceinline__ double readlane_f64(double v, int k)
 __device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t n)
 {
     uint32_t per = (n + 7u) / 8u;
-    uint32_t item = (b & 7u) * per + (b >> 3);
-    return item;  // may be >= n: caller checks
+    return (b & 7u) * per + (b >> 3);  // may be >= n: caller checks
+}
+
+__device__ __forceinline__ int wrap_once(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+
+template <int D>
+__device__ __forceinline__ double horner(const double (&c)[D + 1], double z)
+{
+    double v = c[D];
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) v = fma(v, z, c[k]);
+    return v;
+}
+
+// One visibility's record as seen by its 16-lane row.
+struct RowVis {
+    double pu, pv, pw;
+    bool valid;
+};
+
+// w-plane weight of a visibility for plane a.plane (0 = does not touch the plane)
+template <int W, int D>
+__device__ __forceinline__ double plane_weight(const PlaneArgs &a, double pw, const double *wtab /* LDS (W, D+1) */)
+{
+    if (!a.do_w) return 1.0;
+    if (a.wmode == 0) {
+        const double shift = 1.0 - 0.5 * double(W);
+        const double fl = floor(pw + shift);
+        const int dp = a.plane - (int)fl;
+        if (dp < 0 || dp >= W) return 0.0;
+        const double z = 2.0 * ((pw + shift) - fl) - 1.0;
+        const double *c = wtab + dp * (D + 1);
+        double v = c[D];
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k) v = fma(v, z, c[k]);
+        return v;
+    }
+    double kw = a.coef;
+    for (int m = 0; m < a.nplanes; ++m)
+        if (m != a.plane) kw *= (pw - a.nodes[m]);
+    return kw;
 }
 
 template <int W>
 __global__ void __launch_bounds__(GRID_THREADS) k_grid(PlaneArgs a, const double2 *__restrict__ sval,
                                                         double2 *__restrict__ grid)
 {
+    constexpr int D = kernel_poly_degree_c(W);
     constexpr int L = TILE + W - 1;
-    constexpr int LL = L * L;
+    constexpr int LS = (L & 1) ? L + 1 : L;  // even row stride: conflict-free diagonal walk
+    constexpr int LL = L * LS;
     extern __shared__ double lds[];
     double *lre = lds;
     double *lim = lds + LL;
+    double *wtab = lds + 2 * LL;
 
     uint32_t item = xcd_swizzle(blockIdx.x, gridDim.x);
     if (item >= a.nwork) return;
     const WorkItem wi = a.work[item];
     for (int i = threadIdx.x; i < 2 * LL; i += GRID_THREADS) lds[i] = 0.0;
+    for (int i = threadIdx.x; i < W * (D + 1); i += GRID_THREADS) wtab[i] = a.ktab[i];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = lane & 15, g = lane >> 4;
+    double c[D + 1];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) c[k] = b < W ? a.ktab[b * (D + 1) + k] : 0.0;
     __syncthreads();
 
     const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
     const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const double xs = 2.0 / double(W), shift = 1.0 - 0.5 * double(W);
-    const double dplane = double(a.plane);
+    const double shift = 1.0 - 0.5 * double(W);
 
     for (uint32_t base = wi.begin + wave * 64; base < wi.end; base += (GRID_THREADS / 64) * 64) {
-        const uint32_t j = base + lane;
-        const bool ok = j < wi.end;
-        const double lpu = ok ? a.pu[j] : 0.0;
-        const double lpv = ok ? a.pv[j] : 0.0;
-        const double lpw = (ok && a.do_w) ? a.pw[j] : 0.0;
-        const double2 lval = ok ? sval[j] : make_double2(0.0, 0.0);
-        const int cnt = min(64u, wi.end - base);
-        for (int k = 0; k < cnt; ++k) {
-            const double cpu = readlane_f64(lpu, k), cpv = readlane_f64(lpv, k);
-            double kw = 1.0;
-            if (a.do_w) {
-                const double cpw = readlane_f64(lpw, k);
-                const int dp = a.plane - (int)floor(cpw + shift);
-                if (dp < 0 || dp >= W) continue;  // wave-uniform
-                kw = es_kernel((dplane - cpw) * xs, a.beta);
-            }
-            const int iu0 = (int)floor(cpu + shift), iv0 = (int)floor(cpv + shift);
-            const int lu = wrap_index(iu0, a.nu) - bu, lv = wrap_index(iv0, a.nv) - bv;
-            // lanes 0..W-1: u taps, lanes 16..16+W-1: v taps
-            double kval = 0.0;
-            {
-                const int tap = lane & 15;
-                if (lane < 32 && tap < W) {
-                    const bool isv = (lane & 16) != 0;
-                    const double x = (double((isv ? iv0 : iu0) + tap) - (isv ? cpv : cpu)) * xs;
-                    kval = es_kernel(x, a.beta);
-                }
-            }
-            const double vr = readlane_f64(lval.x, k) * kw, vi = readlane_f64(lval.y, k) * kw;
+        const int nit = int(min(64u, wi.end - base) + 3u) >> 2;
+        for (int it = 0; it < nit; ++it) {
+            const uint32_t j = base + it * 4 + g;
+            const bool valid = j < wi.end;
+            const double pu = valid ? a.pu[j] : 0.0;
+            const double pv = valid ? a.pv[j] : 0.0;
+            const double pw = (valid && a.do_w) ? a.pw[j] : 0.0;
+            const double2 val = valid ? sval[j] : make_double2(0.0, 0.0);
+            double kw = plane_weight<W, D>(a, pw, wtab);
+            if (!valid) kw = 0.0;
+            const double fu = floor(pu + shift), fv = floor(pv + shift);
+            const double zu = 2.0 * ((pu + shift) - fu) - 1.0, zv = 2.0 * ((pv + shift) - fv) - 1.0;
+            double ku = horner<D>(c, zu);
+            const double kv = horner<D>(c, zv) * kw;
+            const int lu = wrap_once((int)fu, a.nu) - bu, lv = wrap_once((int)fv, a.nv) - bv;
+            const double vr = val.x * kv, vi = val.y * kv;
+            const bool col_ok = (b < W) && (kw != 0.0);
+            const int colbase = lu * LS + lv + b;
+            int arow = b;
 #pragma unroll
-            for (int t0 = 0; t0 < W * W; t0 += 64) {
-                const int t = t0 + lane;
-                const int ta = t / W, tb = t - ta * W;
-                const double ku = __shfl(kval, ta & 15);
-                const double kv = __shfl(kval, 16 + (tb & 15));
-                if (t < W * W) {
-                    const double kk = ku * kv;
-                    const int off = (lu + ta) * L + lv + tb;
-                    unsafeAtomicAdd(&lre[off], vr * kk);
-                    unsafeAtomicAdd(&lim[off], vi * kk);
+            for (int i = 0; i < 16; ++i) {
+                if (col_ok && arow < W) {
+                    const int off = colbase + arow * LS;
+                    unsafeAtomicAdd(&lre[off], vr * ku);
+                    unsafeAtomicAdd(&lim[off], vi * ku);
                 }
+                ku = rot1_f64(ku);
+                arow = rot1_i32(arow);
             }
         }
     }
     __syncthreads();
-    double *g = reinterpret_cast<double *>(grid);
-    for (int i = threadIdx.x; i < LL; i += GRID_THREADS) {
-        const double re = lre[i], im = lim[i];
+    double *gp = reinterpret_cast<double *>(grid);
+    for (int i = threadIdx.x; i < L * L; i += GRID_THREADS) {
+        const int la = i / L, lb = i - la * L;
+        const double re = lre[la * LS + lb], im = lim[la * LS + lb];
         if (re != 0.0 || im != 0.0) {
-            const int la = i / L, lb = i - la * L;
             int gu = bu + la, gv = bv + lb;
             gu = gu >= a.nu ? gu % a.nu : gu;
             gv = gv >= a.nv ? gv % a.nv : gv;
             const size_t o = (size_t(gu) * size_t(a.nv) + size_t(gv)) * 2;
-            unsafeAtomicAdd(&g[o], re);
-            unsafeAtomicAdd(&g[o + 1], im);
+            unsafeAtomicAdd(&gp[o], re);
+            unsafeAtomicAdd(&gp[o + 1], im);
         }
     }
 }
@@ -149,86 +200,82 @@ template <int W>
 __global__ void __launch_bounds__(GRID_THREADS) k_degrid(PlaneArgs a, const double2 *__restrict__ grid,
                                                           double2 *__restrict__ sacc)
 {
+    constexpr int D = kernel_poly_degree_c(W);
     constexpr int L = TILE + W - 1;
-    constexpr int LL = L * L;
+    constexpr int LS = (L & 1) ? L + 1 : L;
+    constexpr int LL = L * LS;
     extern __shared__ double lds[];
     double2 *tile = reinterpret_cast<double2 *>(lds);
+    double *wtab = lds + 2 * LL;
 
     uint32_t item = xcd_swizzle(blockIdx.x, gridDim.x);
     if (item >= a.nwork) return;
     const WorkItem wi = a.work[item];
     const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
     const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
-    for (int i = threadIdx.x; i < LL; i += GRID_THREADS) {
+    for (int i = threadIdx.x; i < L * L; i += GRID_THREADS) {
         const int la = i / L, lb = i - la * L;
         int gu = bu + la, gv = bv + lb;
         gu = gu >= a.nu ? gu % a.nu : gu;
         gv = gv >= a.nv ? gv % a.nv : gv;
-        tile[i] = grid[size_t(gu) * size_t(a.nv) + size_t(gv)];
+        tile[la * LS + lb] = grid[size_t(gu) * size_t(a.nv) + size_t(gv)];
     }
-    __syncthreads();
+    for (int i = threadIdx.x; i < W * (D + 1); i += GRID_THREADS) wtab[i] = a.ktab[i];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const double xs = 2.0 / double(W), shift = 1.0 - 0.5 * double(W);
-    const double dplane = double(a.plane);
+    const int b = lane & 15, g = lane >> 4;
+    double c[D + 1];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) c[k] = b < W ? a.ktab[b * (D + 1) + k] : 0.0;
+    __syncthreads();
+
+    const double shift = 1.0 - 0.5 * double(W);
 
     for (uint32_t base = wi.begin + wave * 64; base < wi.end; base += (GRID_THREADS / 64) * 64) {
-        const uint32_t j = base + lane;
-        const bool ok = j < wi.end;
-        const double lpu = ok ? a.pu[j] : 0.0;
-        const double lpv = ok ? a.pv[j] : 0.0;
-        const double lpw = (ok && a.do_w) ? a.pw[j] : 0.0;
-        const int cnt = min(64u, wi.end - base);
-        double outr = 0.0, outi = 0.0;  // lane k keeps the result of visibility base+k
-        for (int k = 0; k < cnt; ++k) {
-            const double cpu = readlane_f64(lpu, k), cpv = readlane_f64(lpv, k);
-            double kw = 1.0;
-            if (a.do_w) {
-                const double cpw = readlane_f64(lpw, k);
-                const int dp = a.plane - (int)floor(cpw + shift);
-                if (dp < 0 || dp >= W) continue;  // wave-uniform
-                kw = es_kernel((dplane - cpw) * xs, a.beta);
-            }
-            const int iu0 = (int)floor(cpu + shift), iv0 = (int)floor(cpv + shift);
-            const int lu = wrap_index(iu0, a.nu) - bu, lv = wrap_index(iv0, a.nv) - bv;
-            double kval = 0.0;
-            {
-                const int tap = lane & 15;
-                if (lane < 32 && tap < W) {
-                    const bool isv = (lane & 16) != 0;
-                    const double x = (double((isv ? iv0 : iu0) + tap) - (isv ? cpv : cpu)) * xs;
-                    kval = es_kernel(x, a.beta);
-                }
-            }
+        const int nit = int(min(64u, wi.end - base) + 3u) >> 2;
+        for (int it = 0; it < nit; ++it) {
+            const uint32_t j = base + it * 4 + g;
+            const bool valid = j < wi.end;
+            const double pu = valid ? a.pu[j] : 0.0;
+            const double pv = valid ? a.pv[j] : 0.0;
+            const double pw = (valid && a.do_w) ? a.pw[j] : 0.0;
+            double kw = plane_weight<W, D>(a, pw, wtab);
+            if (!valid) kw = 0.0;
+            const double fu = floor(pu + shift), fv = floor(pv + shift);
+            const double zu = 2.0 * ((pu + shift) - fu) - 1.0, zv = 2.0 * ((pv + shift) - fv) - 1.0;
+            double ku = horner<D>(c, zu);
+            const double kv = horner<D>(c, zv) * kw;
+            const int lu = wrap_once((int)fu, a.nu) - bu, lv = wrap_once((int)fv, a.nv) - bv;
+            const bool col_ok = (b < W) && (kw != 0.0);
+            const int colbase = lu * LS + lv + b;
+            int arow = b;
             double sr = 0.0, si = 0.0;
 #pragma unroll
-            for (int t0 = 0; t0 < W * W; t0 += 64) {
-                const int t = t0 + lane;
-                const int ta = t / W, tb = t - ta * W;
-                const double ku = __shfl(kval, ta & 15);
-                const double kv = __shfl(kval, 16 + (tb & 15));
-                if (t < W * W) {
-                    const double kk = ku * kv;
-                    const double2 gval = tile[(lu + ta) * L + lv + tb];
-                    sr += gval.x * kk;
-                    si += gval.y * kk;
+            for (int i = 0; i < 16; ++i) {
+                if (col_ok && arow < W) {
+                    const double2 gval = tile[colbase + arow * LS];
+                    sr = fma(gval.x, ku, sr);
+                    si = fma(gval.y, ku, si);
                 }
+                ku = rot1_f64(ku);
+                arow = rot1_i32(arow);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                sr += __shfl_xor(sr, o);
-                si += __shfl_xor(si, o);
+            sr *= kv;
+            si *= kv;
+            sr += rotn_f64<8>(sr);
+            si += rotn_f64<8>(si);
+            sr += rotn_f64<4>(sr);
+            si += rotn_f64<4>(si);
+            sr += rotn_f64<2>(sr);
+            si += rotn_f64<2>(si);
+            sr += rotn_f64<1>(sr);
+            si += rotn_f64<1>(si);
+            if (b == 0 && valid && kw != 0.0) {
+                double2 acc = sacc[j];
+                acc.x += sr;
+                acc.y += si;
+                sacc[j] = acc;
             }
-            if (lane == k) {
-                outr = sr * kw;
-                outi = si * kw;
-            }
-        }
-        if (ok) {
-            double2 acc = sacc[j];
-            acc.x += outr;
-            acc.y += outi;
-            sacc[j] = acc;
         }
     }
 }

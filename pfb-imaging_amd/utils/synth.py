@@ -1,4 +1,5 @@
-"""Synthetic inputs of BASELINE.md section 2 / SURVEY.md section 8(d) (TEST INFRASTRUCTURE).
+"""Synthetic inputs of BASELINE.md section 2 / SURVEY.md section 8(d) (numpy only; used by
+bench.py, the tests and __graft_entry__.smoke()).
 
 Scaled-up version of the reference's own synthetic arrays
 (/root/reference/tests/test_hessian_approx.py:97-102: antenna-difference

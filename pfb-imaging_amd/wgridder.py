@@ -26,7 +26,7 @@ class Gridder:
 
     def __init__(self, uvw, freq, mask=None, *, npix_x, npix_y, pixsize_x, pixsize_y, center_x=0.0, center_y=0.0,
                  epsilon, flip_u=False, flip_v=False, flip_w=False, do_wgridding=True, divide_by_n=True,
-                 sigma_min=1.1, sigma_max=2.6, verbosity=0, force=None):
+                 sigma_min=1.1, sigma_max=2.6, verbosity=0, force=None, force_wmode=None):
         _lib.require_gpu()
         uvw = as_c(uvw, np.float64)
         freq = as_c(freq, np.float64)
@@ -46,6 +46,7 @@ class Gridder:
             flip_u=int(bool(flip_u)), flip_v=int(bool(flip_v)), flip_w=int(bool(flip_w)),
             do_wgridding=int(bool(do_wgridding)), divide_by_n=int(bool(divide_by_n)), verbosity=int(verbosity),
             force_W=0 if force is None else int(force[1]), force_sigma=0.0 if force is None else float(force[0]),
+            force_wmode=0 if force_wmode is None else int(force_wmode) + 1,
         )
         self._h = ct.c_void_p()
         check(lib().pfbhip_gridder_create(ct.byref(p), ptr(uvw), ptr(freq), ptr(mask), ct.byref(self._h)))
@@ -167,7 +168,12 @@ class Gridder:
         i = self.info
         return dict(nu=i["nu"], nv=i["nv"], W=i["W"], beta=i["beta"], sigma=i["sigma"], nplanes=i["nplanes"],
                     wmin=i["wmin"], dw=i["dw"], nshift=i["nshift"], lshift=i["lshift"], mshift=i["mshift"],
-                    tile=i["tile"])
+                    tile=i["tile"], wmode=i["wmode"], wcenter=i["wcenter"], whalf=i["whalf"])
+
+    def planes(self):
+        w = np.empty(self.info["nplanes"], dtype=np.float64)
+        check(lib().pfbhip_gridder_get_planes(self._h, ptr(w)))
+        return w
 
 
 # ---------------------------------------------------------------------------

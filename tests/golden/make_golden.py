@@ -31,7 +31,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from oracle import dft, synth  # noqa: E402
+from oracle import dft  # noqa: E402
+from pfb_imaging_amd.utils import synth  # noqa: E402
 
 
 def conventions():

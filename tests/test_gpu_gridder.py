@@ -16,7 +16,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from oracle import dft, synth  # noqa: E402
+from oracle import dft  # noqa: E402
+from pfb_imaging_amd.utils import synth  # noqa: E402
 from oracle import wgridder as owg  # noqa: E402
 
 
@@ -37,7 +38,9 @@ def gpu_plan(c, **over):
               epsilon=1e-7, flip_u=False, flip_v=True, flip_w=False, do_wgridding=True, divide_by_n=False)
     kw.update(over)
     mask = kw.pop("mask", c["mask"])
-    return Gridder(c["uvw"], c["freq"], mask, **kw), kw, mask
+    g = Gridder(c["uvw"], c["freq"], mask, **kw)
+    kw.pop("force_wmode", None)
+    return g, kw, mask
 
 
 def oracle_plan(c, g, kw, mask):
@@ -65,9 +68,10 @@ def test_binmap_bit_exact(center, do_w):
     g.close()
 
 
-def test_grid_plane_matches_oracle():
+@pytest.mark.parametrize("wmode", [0, 1])
+def test_grid_plane_matches_oracle(wmode):
     c = make()
-    g, kw, mask = gpu_plan(c)
+    g, kw, mask = gpu_plan(c, force_wmode=wmode)
     o = oracle_plan(c, g, kw, mask)
     sval = o.prep_vis(c["vis"], c["wgt"])
     for plane in (0, g.info["nplanes"] // 2, g.info["nplanes"] - 1):
@@ -78,10 +82,15 @@ def test_grid_plane_matches_oracle():
 
 
 @pytest.mark.parametrize("center", [(0.0, 0.0), (0.01, -0.02)])
-@pytest.mark.parametrize("do_w,divn", [(True, False), (True, True), (False, False)])
-def test_vis2dirty_dirty2vis_vs_dft(center, do_w, divn):
+@pytest.mark.parametrize("do_w,divn,wmode", [(True, False, 0), (True, True, 0), (True, False, 1), (True, True, 1),
+                                             (False, False, None)])
+def test_vis2dirty_dirty2vis_vs_dft(center, do_w, divn, wmode):
+    """Both w-plane schemes (ES-kernel planes / polynomial planes through Chebyshev nodes)."""
     c = make()
-    g, kw, mask = gpu_plan(c, center_x=center[0], center_y=center[1], do_wgridding=do_w, divide_by_n=divn)
+    g, kw, mask = gpu_plan(c, center_x=center[0], center_y=center[1], do_wgridding=do_w, divide_by_n=divn,
+                           force_wmode=wmode)
+    if do_w:
+        assert g.info["wmode"] == wmode
     o = oracle_plan(c, g, kw, mask)
     d = g.vis2dirty(c["vis"], c["wgt"])
     assert rel(d, o.vis2dirty(c["vis"], c["wgt"])) < 1e-10
@@ -99,8 +108,10 @@ def test_vis2dirty_dirty2vis_vs_dft(center, do_w, divn):
 
 
 @pytest.mark.parametrize("eps", [1e-3, 1e-5, 1e-9])
-def test_epsilon_contract(eps):
-    c = make(nrow=1500)
+@pytest.mark.parametrize("widen,zscale", [(40.0, 0.3), (2.0, 1e-3)])
+def test_epsilon_contract(eps, widen, zscale):
+    """Requested accuracy holds for wide fields (kernel w-planes win) and narrow ones (polynomial planes win)."""
+    c = make(nrow=1500, widen=widen, zscale=zscale)
     g, kw, mask = gpu_plan(c, epsilon=eps)
     d = g.vis2dirty(c["vis"], c["wgt"])
     ref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], mask, c["nx"], c["ny"], c["cell"], c["cell"],
@@ -168,8 +179,19 @@ def test_psfvis_identity():
         v = dirty2vis(uvw=c["uvw"], freq=c["freq"], dirty=x, pixsize_x=c["cell"], pixsize_y=c["cell"], center_x=x0,
                       center_y=y0, flip_u=flip_u, flip_v=flip_v, flip_w=flip_w, epsilon=eps, do_wgridding=True,
                       divide_by_n=False)
+        # the analytic ramp in extended precision: at these baseline lengths (3e5 wavelengths) the
+        # float64 expression of gridder.py:616-629 is itself only good to ~2e-10
+        ld = np.longdouble
+        r2 = ld(x0) ** 2 + ld(y0) ** 2
+        nm1 = -r2 / (1 + np.sqrt(1 - r2))
+        ph = (c["uvw"][:, 0:1].astype(ld) * ld(x0) + c["uvw"][:, 1:2].astype(ld) * ld(y0)
+              - c["uvw"][:, 2:].astype(ld) * nm1) * (c["freq"][None, :].astype(ld) / ld(299792458.0))
+        ph = ph - np.rint(ph)
+        exact = np.exp(-2j * np.pi * ph.astype(np.float64))
+        assert np.abs(exact - v).max() <= eps
+        # and the float64 formula the reference uses for its PSF visibilities agrees to its own rounding
         psf_vis = np.conj(psf_visibilities(c["uvw"], c["freq"], x0, y0, flip_u, flip_v))
-        assert np.abs(psf_vis - v).max() <= eps
+        assert np.abs(psf_vis - v).max() <= 1e-9
 
 
 def test_edge_cases():
