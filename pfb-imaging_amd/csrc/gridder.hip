@@ -831,6 +831,10 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         for (int64_t t = 0; t < info.ntiles; ++t)
             for (uint32_t b = tstart[t]; b < tstart[t + 1]; b += CHUNK)
                 work.push_back(WorkItem{uint32_t(t), b, std::min<uint32_t>(b + CHUNK, tstart[t + 1]), 0});
+        // Longest-processing-time-first: heavy chunks are dispatched first, the many tiny ones of the
+        // sparse outer uv-plane fill the tail (the uv density is strongly peaked at the centre).
+        std::stable_sort(work.begin(), work.end(),
+                         [](const WorkItem &x, const WorkItem &y) { return (x.end - x.begin) > (y.end - y.begin); });
         const size_t na1 = size_t(std::max<int64_t>(info.nactive, 1));
         g->d_pu.alloc(na1);
         g->d_pv.alloc(na1);

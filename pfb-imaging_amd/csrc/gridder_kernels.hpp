@@ -70,13 +70,11 @@ __device__ __forceinline__ double rotn_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
-// Blocks b and b+8 share an XCD (round-robin dispatch): give every XCD a contiguous run of
-// work items so neighbouring tiles (shared halo lines) meet in one L2.  Speed only.
-__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t n)
-{
-    uint32_t per = (n + 7u) / 8u;
-    return (b & 7u) * per + (b >> 3);  // may be >= n: caller checks
-}
+// Work items are sorted by decreasing size and taken in block order: blocks are dealt
+// round-robin over the 8 XCDs, so every XCD gets the same mix of heavy and light items.  (A
+// contiguous run of tile-sorted items per XCD was measured 2x slower: the uv density peaks at
+// the centre, so two XCDs got nearly all the work.)
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t) { return b; }
 
 __device__ __forceinline__ int wrap_once(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
