@@ -1,0 +1,85 @@
+"""Worker for tests/test_parallel_cpu.py: run under torch.distributed.run with 2 ranks (gloo, CPU)."""
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from pfb_imaging_amd.operators.band_worker import BandWorkerPool  # noqa: E402
+from pfb_imaging_amd.parallel import BandComm, local_bands  # noqa: E402
+
+
+class FakeWorker:
+    """Stands in for the GPU band worker: a diagonal 'Hessian' and an affine 'residual' in numpy
+    (the reference fakes its Hessian the same way: tests/test_pcg_solver.py:10-46)."""
+
+    def __init__(self, nthreads):
+        self.scale = None
+
+    def set_band(self, dirty, parts, hess_parts=None):
+        self.dirty = dirty
+        self.scale = parts
+
+    def init_hess(self, partitions, nx, ny, nx_psf, ny_psf, eta, wsum):
+        self.d = partitions + eta
+
+    def hess_dot(self, x):
+        return (self.d * x)[None]
+
+    def cg(self, rhs, x0, tol, maxit, minit, verbosity):
+        return rhs / self.d
+
+    def residual(self, model, cell_rad, epsilon, do_wgridding, double_accum):
+        return self.dirty - self.scale * model
+
+
+def main():
+    comm = BandComm.from_env(transport="gloo")
+    assert comm.world_size == 2
+    nband, nx, ny = 5, 6, 4
+    rng = np.random.default_rng(0)  # same data on every rank
+    x = rng.standard_normal((nband, nx, ny))
+    assert local_bands(nband, comm.rank, 2) == ([0, 2, 4] if comm.rank == 0 else [1, 3])
+
+    # collectives
+    total = comm.reduce_sum(np.full((3, 3), comm.rank + 1.0), root=0)
+    if comm.rank == 0:
+        assert np.array_equal(total, np.full((3, 3), 3.0))
+    else:
+        assert total is None
+    assert np.array_equal(comm.allreduce_sum(np.full(4, comm.rank + 1.0)), np.full(4, 3.0))
+    assert comm.max_over_ranks(comm.rank * 2.5) == 2.5
+    assert comm.sum_over_ranks(1.0) == 2.0
+
+    # band pool: each rank owns bands b % 2 == rank; cube-level results are identical on all ranks
+    pool = BandWorkerPool(nband, comm=comm, worker_cls=FakeWorker)
+    assert sorted(pool.workers) == local_bands(nband, comm.rank, 2)
+    diag = [1.0 + b + rng.random((nx, ny)) for b in range(nband)]
+    pool.init_hess(diag, nx, ny, 2 * nx, 2 * ny, np.full(nband, 0.5), [None] * nband)
+    got = pool.hess_dot(x)
+    ref = np.stack([(diag[b] + 0.5) * x[b] for b in range(nband)])
+    np.testing.assert_allclose(got, ref, rtol=1e-14)
+    sol = pool.hess_cg(ref, None, 1e-6, 10, 1, 0)
+    np.testing.assert_allclose(sol, x, rtol=1e-13)
+
+    dirty = rng.standard_normal((nband, 1, nx, ny))
+    model = rng.standard_normal((nband, 1, nx, ny))
+    scales = [2.0 + b for b in range(nband)]
+    pool.set_bands(dirty, scales)
+    res = pool.residual(model, 1e-6)
+    ref = np.stack([dirty[b] - scales[b] * model[b] for b in range(nband)])
+    np.testing.assert_allclose(res, ref, rtol=1e-14)
+    mfs = pool.residual_mfs(model, 1e-6, wsum=4.0, root=0)
+    if comm.rank == 0:
+        np.testing.assert_allclose(mfs, ref.sum(axis=0) / 4.0, rtol=1e-13)
+    else:
+        assert mfs is None
+    comm.barrier()
+    print(f"rank {comm.rank} ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()

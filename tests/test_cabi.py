@@ -1,0 +1,126 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol
+include/pfbhip.h declares, its structs match the ctypes mirror, and it fails loudly without a GPU."""
+
+import ctypes as ct
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pfbhip.h")
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pfbhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pfb_imaging_amd import _lib
+
+    L = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 45
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(_lib.SYMBOLS) == declared
+
+
+def test_struct_layout_matches_header(tmp_path):
+    from pfb_imaging_amd import _lib
+
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "pfbhip.h"\n'
+        "int main(void){\n"
+        'printf("%zu %zu %zu %zu %zu\\n", sizeof(pfbhip_gridder_params), offsetof(pfbhip_gridder_params, epsilon),'
+        " offsetof(pfbhip_gridder_params, flip_u), offsetof(pfbhip_gridder_params, force_wmode),"
+        " offsetof(pfbhip_gridder_params, force_sigma));\n"
+        'printf("%zu %zu %zu %zu %zu\\n", sizeof(pfbhip_gridder_info), offsetof(pfbhip_gridder_info, W),'
+        " offsetof(pfbhip_gridder_info, beta), offsetof(pfbhip_gridder_info, wmode),"
+        " offsetof(pfbhip_gridder_info, device_bytes));\n"
+        'printf("%zu %zu\\n", sizeof(pfbhip_cg_info), offsetof(pfbhip_cg_info, eps));\n'
+        "return 0;}\n"
+    )
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    P, I, C = _lib.GridderParams, _lib.GridderInfo, _lib.CGInfo
+    expect = [ct.sizeof(P), P.epsilon.offset, P.flip_u.offset, P.force_wmode.offset, P.force_sigma.offset,
+              ct.sizeof(I), I.W.offset, I.beta.offset, I.wmode.offset, I.device_bytes.offset, ct.sizeof(C), C.eps.offset]
+    assert [int(v) for v in out] == expect
+
+
+def test_no_gpu_paths_fail_loudly_or_work_on_host():
+    from pfb_imaging_amd import _lib, fft, misc
+
+    L = _lib.lib()
+    assert fft.good_size(11468) == 11520
+    assert fft.good_size(127, True) == 128
+    misc.resize_thread_pool(7)
+    assert misc.thread_pool_size() == 7
+    assert misc.empty_noncritical((3, 4), "c16").shape == (3, 4)
+    # invalid arguments are reported through the status / last-error channel (no exceptions cross the ABI)
+    st = L.pfbhip_gridder_get_info(None, None)
+    assert st == 1 and "NULL" in _lib.last_error()
+    with pytest.raises(ValueError):
+        _lib.check(st)
+    if _lib.device_count() == 0:
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            _lib.require_gpu()
+        from pfb_imaging_amd.wgridder import vis2dirty
+
+        with pytest.raises(RuntimeError):
+            vis2dirty(uvw=np.zeros((3, 3)), freq=np.ones(1), vis=np.zeros((3, 1), complex), npix_x=16, npix_y=16,
+                      pixsize_x=1e-5, pixsize_y=1e-5, epsilon=1e-5, do_wgridding=True)
+
+
+def test_product_never_imports_oracle():
+    """The product path must not reach into the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "pfb-imaging_amd")
+    bad = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "libpfb_oracle" in text:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+    code = ("import sys; sys.path.insert(0, %r); import pfb_imaging_amd.operators.hessian, pfb_imaging_amd.operators.gridder, "
+            "pfb_imaging_amd.operators.band_worker, pfb_imaging_amd.operators.psf, pfb_imaging_amd.utils.weighting; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)" % ROOT)
+    subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_host_side_helpers():
+    from pfb_imaging_amd.operators import LinearOperator, Preconditioner, require_protocol
+    from pfb_imaging_amd.operators.gridder import psf_visibilities, wgridder_conventions
+    from pfb_imaging_amd.operators.hessian import hessian_slice, taperf
+
+    assert wgridder_conventions(0.1, -0.2) == (False, True, False, -0.1, 0.2)
+    rng = np.random.default_rng(0)
+    uvw = rng.standard_normal((10, 3)) * 100
+    freq = np.array([1e9, 1.1e9])
+    assert np.array_equal(psf_visibilities(uvw, freq, 0.0, 0.0), np.ones((10, 2)))
+    x0, y0 = -0.1, 0.17
+    n = np.sqrt(1 - x0**2 - y0**2)
+    ref = np.exp(2j * np.pi * freq[None] / 299792458.0 * (uvw[:, 0:1] * x0 + uvw[:, 1:2] * y0 - uvw[:, 2:] * (n - 1)))
+    np.testing.assert_allclose(psf_visibilities(uvw, freq, x0, y0), ref)
+    t = taperf((64, 48), 8)
+    assert t.shape == (64, 48) and t[32, 24] == 1.0 and t[0, 0] < 1e-2
+    # zero-input shortcut never touches the device (hessian.py:47-48)
+    assert not hessian_slice(np.zeros((8, 8))).any()
+
+    class Bad:
+        def dot(self, x):
+            return x
+
+    with pytest.raises(TypeError, match="hdot"):
+        require_protocol(Bad(), LinearOperator, "hess")
+    with pytest.raises(TypeError, match="Preconditioner"):
+        require_protocol(Bad(), Preconditioner, "precond")

@@ -1,0 +1,228 @@
+"""GPU parity tests of the FFT / PSF-convolution operator family and the band-worker pool.
+
+Oracle: oracle.fftconv (numpy rfft2 / irfft2 restatement of the reference's operators).
+Tolerance: 1e-11 relative (double-precision FFTs of different factorisations), the reference's
+own tests use rtol 1e-12..1e-5 (test_hess_tree_ray.py:22-80, test_hessian_tree.py:20-66).
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fftconv  # noqa: E402
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def _psf_case(nband=2, nx=48, ny=40, nxp=96, nyp=80, seed=0):
+    rng = np.random.default_rng(seed)
+    psf = rng.standard_normal((nband, nxp, nyp))
+    psfhat = np.fft.rfft2(np.fft.ifftshift(psf, axes=(1, 2)), axes=(1, 2))
+    x = rng.standard_normal((nband, nx, ny))
+    beam = 0.5 + rng.random((nband, nx, ny))
+    return psf, psfhat, np.abs(psfhat), x, beam
+
+
+def test_r2c_c2r_good_size():
+    from pfb_imaging_amd.fft import c2r, good_size, r2c
+
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((3, 36, 50))
+    ah = r2c(a, axes=(1, 2), forward=True, inorm=0)
+    assert ah.shape == (3, 36, 26)
+    assert rel(ah, np.fft.rfft2(a, axes=(1, 2))) < 1e-13
+    back = c2r(ah, axes=(1, 2), forward=False, lastsize=50, inorm=2, allow_overwriting_input=True)
+    assert rel(back, a) < 1e-13
+    out = np.empty_like(ah)
+    assert r2c(a, axes=(-2, -1), out=out) is out
+    assert good_size(11468) == 11520 and good_size(127) == 128 and good_size(1000, True) == 1000
+    with pytest.raises(NotImplementedError):
+        r2c(a, axes=(0, 1))
+
+
+def test_psf_convolve_slice_cube_fscube():
+    """psf.py:8-96 == crop(irfft2(rfft2(pad(x)) psfhat)) (its jax twin, psf.py:99-104)."""
+    from pfb_imaging_amd.operators.psf import psf_convolve_cube, psf_convolve_fscube, psf_convolve_slice
+
+    psf, psfhat, abspsf, x, beam = _psf_case()
+    nband, nx, ny = x.shape
+    nxp, nyp = psf.shape[1:]
+    ref = fftconv.psf_convolve(x, psfhat, nxp, nyp)
+    xout = np.zeros((nx, ny))
+    r = psf_convolve_slice(np.zeros((nxp, nyp)), np.zeros_like(psfhat[0]), xout, psfhat[0], nyp, x[0])
+    assert r is xout and rel(xout, ref[0]) < 1e-11
+    cube = np.zeros_like(x)
+    psf_convolve_cube(np.zeros((nband, nxp, nyp)), np.zeros_like(psfhat), cube, psfhat, nyp, x)
+    assert rel(cube, ref) < 1e-11
+    fs = np.zeros((nband, 1, nx, ny))
+    psf_convolve_fscube(None, None, fs, psfhat[:, None], nyp, x[:, None])
+    assert rel(fs[:, 0], ref) < 1e-11
+    # delta PSF -> identity (test_hessian_tree.py:20-33)
+    d = np.zeros((nxp, nyp))
+    d[0, 0] = 1.0
+    dh = np.fft.rfft2(d)
+    psf_convolve_slice(None, None, xout, dh, nyp, x[1])
+    assert rel(xout, x[1]) < 1e-12
+
+
+def test_hessian_psf_slice_and_direct():
+    from pfb_imaging_amd.operators.hessian import hess_direct_slice, hessian_psf_slice, taperf
+
+    psf, psfhat, abspsf, x, beam = _psf_case()
+    nxp, nyp = psf.shape[1:]
+    for bm, eta in ((None, None), (beam[0], 0.3), (beam[0], 0.0)):
+        got = hessian_psf_slice(x[0], xout=np.zeros_like(x[0]), abspsf=abspsf[0], beam=bm, lastsize=nyp, eta=eta)
+        assert rel(got, fftconv.hessian_psf_slice(x[0], abspsf[0], nyp, beam=bm, eta=eta)) < 1e-11
+    taper = taperf(x[0].shape, 8)
+    assert np.allclose(taper, fftconv.taperf(x[0].shape, 8))
+    for mode in ("forward", "backward"):
+        got = hess_direct_slice(x[0], xout=np.zeros_like(x[0]), abspsf=abspsf[0], taperxy=taper, lastsize=nyp,
+                                eta=2.5, mode=mode)
+        assert rel(got, fftconv.hess_direct_slice(x[0], abspsf[0], nyp, taper, 2.5, mode)) < 1e-10
+
+
+def test_hesspsf_dot_idot():
+    """HessPSF (hessian.py:251-436): dot aliases self.xout, idot returns a copy, psf-mode idot
+    inverts dot to CG tolerance, protocol conformance."""
+    from pfb_imaging_amd.operators import LinearOperator, Preconditioner, require_protocol
+    from pfb_imaging_amd.operators.hessian import HessPSF
+
+    psf, psfhat, abspsf, x, beam = _psf_case(nband=2, nx=32, ny=32, nxp=64, nyp=64, seed=3)
+    # make the operator well conditioned: PSF = delta + small perturbation
+    abspsf = 1.0 + 0.2 * abspsf / abspsf.max()
+    eta = np.array([0.1, 0.2])
+    h = HessPSF(32, 32, abspsf, beam=beam, eta=eta, cgtol=1e-10, cgmaxit=400)
+    require_protocol(h, Preconditioner, "precond")
+    assert isinstance(h, LinearOperator)
+    out = h.dot(x)
+    assert out is h.xout
+    ref = fftconv.hess_psf_dot(x, abspsf, 64, beam=beam, eta=eta)
+    assert rel(out, ref) < 1e-11
+    assert rel(h.hdot(x), ref) < 1e-11
+    # 2-D input is promoted for nband == 1
+    h1 = HessPSF(32, 32, abspsf[:1], beam=None, eta=0.5)
+    assert rel(h1.dot(x[0])[0], fftconv.hess_psf_dot(x[:1], abspsf[:1], 64, None, 0.5)[0]) < 1e-11
+    rhs = ref.copy()
+    sol = h.idot(rhs, mode="psf")
+    assert sol is not h.xout
+    assert rel(sol, x) < 1e-6
+    d = h.idot(rhs, mode="direct")
+    assert d.shape == x.shape and np.isfinite(d).all()
+    with pytest.raises(ValueError):
+        h.idot(rhs, mode="nonsense")
+    with pytest.raises(ValueError):
+        h.dot(np.zeros((1, 2, 32, 32)))
+
+
+def _tree_parts(nx, ny, nxp, nyp, nparts, ncorr, seed, delta=False):
+    rng = np.random.default_rng(seed)
+    parts = []
+    for _ in range(nparts):
+        if delta:
+            psfhat = np.ones((ncorr, nxp, nyp // 2 + 1))
+        else:
+            psfhat = np.abs(np.fft.rfft2(rng.standard_normal((ncorr, nxp, nyp)), axes=(1, 2)))
+        parts.append({"psfhat": psfhat, "beam": 0.5 + rng.random((ncorr, nx, ny)) if not delta else np.ones((ncorr, nx, ny)),
+                      "wsum": 1.0 + rng.random(ncorr) if not delta else np.ones(ncorr)})
+    return parts
+
+
+def test_hessian_tree():
+    """test_hessian_tree.py:20-66: delta-PSF identity, + eta, two identical partitions == one, 2-D input;
+    plus a random multi-partition / multi-correlation case against the numpy restatement."""
+    from pfb_imaging_amd.operators.hessian import HessianTree
+
+    nx = ny = 16
+    nxp = nyp = 32
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, nx, ny))
+    one = _tree_parts(nx, ny, nxp, nyp, 1, 1, 0, delta=True)
+    np.testing.assert_allclose(HessianTree(one, nx, ny, nxp, nyp).dot(x), x, atol=1e-6)
+    np.testing.assert_allclose(HessianTree(one, nx, ny, nxp, nyp, eta=0.5).dot(x), 1.5 * x, atol=1e-6)
+    np.testing.assert_allclose(HessianTree(one + one, nx, ny, nxp, nyp).dot(x), x, atol=1e-6)
+    assert HessianTree(one, nx, ny, nxp, nyp).dot(x[0]).shape == (1, nx, ny)
+    with pytest.raises(ValueError):
+        HessianTree([], nx, ny, nxp, nyp)
+    parts = _tree_parts(nx, ny, nxp, nyp, 3, 2, 1)
+    x2 = rng.standard_normal((2, nx, ny))
+    for wsum in (None, 7.0):
+        got = HessianTree(parts, nx, ny, nxp, nyp, eta=0.2, wsum=wsum).dot(x2)
+        assert rel(got, fftconv.hessian_tree_dot(x2, parts, nxp, nyp, eta=0.2, wsum=wsum)) < 1e-11
+    # wsum override halves the output (test_hess_tree_ray.py:22-33)
+    a = HessianTree(parts, nx, ny, nxp, nyp, wsum=1.0).dot(x2)
+    b = HessianTree(parts, nx, ny, nxp, nyp, wsum=2.0).dot(x2)
+    np.testing.assert_allclose(a, 2 * b, rtol=1e-12)
+
+
+def test_hess_tree_ray_pool_and_cg():
+    """test_hess_tree_ray.py:36-80: cube-level facade == per-band HessianTree == HessPSF (single
+    partition); cg solves hess @ update = rhs; pool geometry errors."""
+    from pfb_imaging_amd.operators.band_worker import BandWorkerPool
+    from pfb_imaging_amd.operators.hessian import HessianTree, HessPSF, HessTreeRay
+
+    nband, nx, ny, nxp, nyp = 3, 16, 16, 32, 32
+    rng = np.random.default_rng(4)
+    ppb = [_tree_parts(nx, ny, nxp, nyp, 1, 1, 10 + b) for b in range(nband)]
+    for b in range(nband):  # well conditioned
+        ppb[b][0]["psfhat"] = 1.0 + 0.3 * ppb[b][0]["psfhat"] / ppb[b][0]["psfhat"].max()
+    etas = np.array([0.1, 0.2, 0.3])
+    wsum_tot = sum(p[0]["wsum"][0] for p in ppb)
+    hr = HessTreeRay(ppb, nx, ny, nxp, nyp, etas=etas, wsums=wsum_tot, cg_tol=1e-10, cg_maxit=300)
+    x = rng.standard_normal((nband, nx, ny))
+    got = hr.dot(x)
+    for b in range(nband):
+        loc = HessianTree(ppb[b], nx, ny, nxp, nyp, eta=etas[b], wsum=wsum_tot).dot(x[b])[0]
+        np.testing.assert_allclose(got[b], loc, rtol=1e-12, atol=1e-13)
+    abspsf = np.stack([p[0]["psfhat"][0] for p in ppb]) / wsum_tot
+    beam = np.stack([p[0]["beam"][0] for p in ppb])
+    hp = HessPSF(nx, ny, abspsf, beam=beam, eta=etas)
+    np.testing.assert_allclose(got, hp.dot(x).copy(), rtol=1e-10, atol=1e-12)
+    sol = hr.cg(got, tol=1e-10, maxit=300, minit=1)
+    assert rel(sol, x) < 1e-6
+    x0 = rng.standard_normal((nband, nx, ny))
+    x0c = x0.copy()
+    sol2 = hr.cg(got, x0=x0, tol=1e-10, maxit=300, minit=1)
+    assert rel(sol2, x) < 1e-6 and np.array_equal(x0, x0c)
+    ref = fftconv.pcg(lambda z: fftconv.hessian_tree_dot(z, ppb[0], nxp, nyp, eta=etas[0], wsum=wsum_tot)[0], got[0],
+                      tol=1e-10, maxit=300, minit=1)
+    assert rel(sol[0], ref) < 1e-6
+    with pytest.raises(ValueError):
+        HessTreeRay(ppb, nx, ny, nxp, nyp, workers=BandWorkerPool(2))
+    with pytest.raises(ValueError):
+        HessTreeRay(None, nx, ny, nxp, nyp)
+    assert isinstance(hr.get_mem(), list)
+
+
+def test_band_pool_residual_and_mfs():
+    """BandWorkerPool.residual == per-band residual_from_partitions; residual_mfs == sum_b / wsum
+    (core/deconv.py:313-321)."""
+    from pfb_imaging_amd.operators.band_worker import BandWorkerPool
+    from pfb_imaging_amd.operators.gridder import residual_from_partitions
+
+    nband, nx, ny = 2, 16, 16
+    rng = np.random.default_rng(8)
+
+    def part(seed):
+        r = np.random.default_rng(seed)
+        n = 150
+        return {"UVW": r.standard_normal((n, 3)) * 100.0, "FREQ": np.array([1.0e9, 1.1e9]),
+                "WEIGHT": np.abs(r.standard_normal((1, n, 2))) + 0.1, "MASK": (r.random((n, 2)) > 0.1).astype(np.uint8),
+                "BEAM": 0.5 + r.random((1, nx, ny)), "attrs": {"l0": 0.0, "m0": 0.0}}
+
+    parts = [[part(1), part(2)], [part(3)]]
+    dirty = rng.standard_normal((nband, 1, nx, ny))
+    model = rng.standard_normal((nband, 1, nx, ny))
+    pool = BandWorkerPool(nband)
+    pool.set_bands(dirty, parts)
+    res = pool.residual(model, 1.0e-6)
+    assert res.shape == (nband, 1, nx, ny)
+    for b in range(nband):
+        np.testing.assert_allclose(res[b], residual_from_partitions(dirty[b], parts[b], model[b], 1.0e-6), rtol=1e-9,
+                                   atol=1e-9)
+    mfs = pool.residual_mfs(model, 1.0e-6, wsum=3.0)
+    np.testing.assert_allclose(mfs, res.sum(axis=0) / 3.0, rtol=1e-12, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        pool.init_psi(nx, ny, ["self"], 2)

@@ -1,0 +1,193 @@
+"""CPU tests that pin the oracle (no GPU): the algorithm restatement against the exact DFT, the
+reference's analytic identities, and the committed golden vectors."""
+
+import numpy as np
+import pytest
+
+from oracle import dft, fftconv
+from oracle import weighting as ow
+from oracle import wgridder as owg
+from pfb_imaging_amd.utils import synth
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def _case(nrow=2000, nchan=2, npix=48, zscale=0.3, widen=40.0, seed=1):
+    c = synth.make_case(nrow, nchan, npix, zscale=zscale, seed=seed)
+    c["cell"] *= widen
+    return c
+
+
+@pytest.mark.parametrize("wmode", [0, 1])
+@pytest.mark.parametrize("center", [(0.0, 0.0), (0.01, -0.02)])
+def test_restatement_vs_dft(wmode, center):
+    c = _case()
+    kw = dict(uvw=c["uvw"], freq=c["freq"], pixsize_x=c["cell"], pixsize_y=c["cell"], center_x=center[0],
+              center_y=center[1], epsilon=1e-7, flip_v=True, do_wgridding=True, divide_by_n=False, force_wmode=wmode)
+    d = owg.vis2dirty(vis=c["vis"], wgt=c["wgt"], mask=c["mask"], npix_x=48, npix_y=48, **kw)
+    ref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], c["mask"], 48, 48, c["cell"], c["cell"], center[0],
+                            center[1], False, True, False, True, False)
+    assert rel(d, ref) < 1e-7
+    v = owg.dirty2vis(dirty=c["x"], mask=c["mask"], **kw)
+    refv = dft.dft_dirty2vis(c["uvw"], c["freq"], c["x"], c["cell"], c["cell"], center[0], center[1], False, True, False,
+                             True, False)
+    refv[c["mask"] == 0] = 0
+    assert rel(v, refv) < 1e-7
+
+
+def test_mode_choice_and_exact_kernel_option():
+    """Narrow fields pick polynomial w-planes (fewer planes than the kernel support), wide fields
+    the ES-kernel planes; the polynomial kernel form agrees with the exact kernel."""
+    narrow = _case(zscale=1e-3, widen=1.0)
+    p = owg.Plan(narrow["uvw"], narrow["freq"], narrow["mask"], 48, 48, narrow["cell"], narrow["cell"], epsilon=1e-7,
+                 flip_v=True, divide_by_n=False)
+    assert p.p.wmode == 1 and p.p.nplanes < p.p.W
+    wide = _case()
+    q = owg.Plan(wide["uvw"], wide["freq"], wide["mask"], 48, 48, wide["cell"], wide["cell"], 0.01, -0.02, epsilon=1e-7,
+                 flip_v=True, divide_by_n=False)
+    assert q.p.wmode == 0 and q.p.nplanes > q.p.W
+    q2 = owg.Plan(wide["uvw"], wide["freq"], wide["mask"], 48, 48, wide["cell"], wide["cell"], 0.01, -0.02,
+                  epsilon=1e-7, flip_v=True, divide_by_n=False, use_poly_kernel=False)
+    assert rel(q.vis2dirty(wide["vis"], wide["wgt"]), q2.vis2dirty(wide["vis"], wide["wgt"])) < 1e-9
+
+
+def test_adjointness_linearity_no_wgridding():
+    c = _case()
+    p = owg.Plan(c["uvw"], c["freq"], c["mask"], 48, 48, c["cell"], c["cell"], 0.0, 0.0, 1e-7, False, True, False,
+                 False, False)
+    y = c["vis"] * c["mask"]
+    lhs = np.vdot(p.dirty2vis(c["x"]), y).real
+    rhs = np.vdot(c["x"], p.vis2dirty(y))
+    assert abs(lhs - rhs) < 1e-12 * abs(rhs)
+    ref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], c["mask"], 48, 48, c["cell"], c["cell"], 0, 0, False,
+                            True, False, False, False)
+    assert rel(p.vis2dirty(c["vis"], c["wgt"]), ref) < 1e-7
+
+
+def test_reference_conventions_golden(golden_dir):
+    """test_wgridder_conventions (test_hessian_approx.py:128-185) on the golden vectors: restatement
+    within atol 1e-4 at epsilon 1e-6 (two of the five offsets to keep the CPU suite short); the
+    golden vectors themselves equal the reference's explicit formula."""
+    gold = np.load(f"{golden_dir}/conventions_two_sources.npz")
+    uvw, freq, npix, pix = gold["uvw"], gold["freq"], int(gold["npix"]), float(gold["pixsize"])
+    dirty = np.zeros((npix, npix))
+    dirty[npix // 2, npix // 2] = 1.0
+    dirty[npix // 4, npix // 4] = 1.0
+    for k in (0, 2):
+        l0, m0 = gold["offsets"][k]
+        # explicit_wdegridder, test_hessian_approx.py:44-67
+        ve = np.zeros_like(gold["vis"][k])
+        for xi, yi in ((npix // 2, npix // 2), (npix // 4, npix // 4)):
+            lc = -l0 + (-npix / 2 + xi) * pix
+            mc = m0 + (-npix / 2 + yi) * pix
+            nc = np.sqrt(1 - lc * lc - mc * mc)
+            ph = (uvw[:, 0:1] * lc - uvw[:, 1:2] * mc - uvw[:, 2:3] * (nc - 1)) * freq[None, :] / 299792458.0
+            ve += np.exp(-2j * np.pi * ph) / nc
+        assert np.abs(ve - gold["vis"][k]).max() < 1e-8
+        vis = owg.dirty2vis(uvw=uvw, freq=freq, dirty=dirty, pixsize_x=pix, pixsize_y=pix, center_x=-l0, center_y=-m0,
+                            epsilon=1e-6, do_wgridding=True, flip_u=False, flip_v=True, flip_w=False, divide_by_n=True)
+        np.testing.assert_allclose(vis.real, gold["vis"][k].real, atol=1e-4)
+        np.testing.assert_allclose(vis.imag, gold["vis"][k].imag, atol=1e-4)
+
+
+def test_hessian_equals_psf_convolution():
+    """test_hessian (test_hessian_approx.py:234-307): grid o degrid of a delta (no w-gridding) equals
+    the FFT convolution with the PSF gridded from unit visibilities."""
+    c = synth.make_case(1500, 2, 32, seed=3)
+    nx = ny = 32
+    nxp = nyp = 64
+    cell = c["cell"]
+    kw = dict(uvw=c["uvw"], freq=c["freq"], pixsize_x=cell, pixsize_y=cell, epsilon=1e-10, flip_v=True,
+              do_wgridding=False, divide_by_n=False)
+    psf = owg.vis2dirty(vis=np.ones_like(c["vis"]), npix_x=nxp, npix_y=nyp, **kw)
+    psfhat = np.fft.rfft2(np.fft.ifftshift(psf))
+    x = np.zeros((nx, ny))
+    x[nx // 2, ny // 2] = 1.0
+    res1 = owg.vis2dirty(vis=owg.dirty2vis(dirty=x, **kw), npix_x=nx, npix_y=ny, **kw)
+    res2 = fftconv.psf_convolve(x, psfhat, nxp, nyp)
+    scale = np.abs(res2).max()
+    assert np.allclose(1 + (res2 - res1) / scale, 1)
+
+
+def test_synth_partition_and_wstack_golden(golden_dir):
+    g = np.load(f"{golden_dir}/synth_partition.npz")
+    d = owg.vis2dirty(uvw=g["uvw"], freq=g["freq"], vis=g["vis"][0], wgt=g["wgt"][0], mask=g["mask"], npix_x=16,
+                      npix_y=16, pixsize_x=float(g["cell"]), pixsize_y=float(g["cell"]), epsilon=1e-7, flip_v=True,
+                      do_wgridding=True, divide_by_n=False)
+    assert np.abs(d - g["dirty"]).max() < 1e-7 * np.abs(g["dirty"]).max()
+    w = np.load(f"{golden_dir}/wstack_small.npz")
+    p = owg.Plan(w["uvw"], w["freq"], w["mask"], 48, 48, float(w["cell"]), float(w["cell"]), w["center"][0],
+                 w["center"][1], 1e-7, False, True, False, True, False)
+    assert rel(p.vis2dirty(w["vis"], w["wgt"]), w["dirty"]) < 1e-7
+    assert rel(p.dirty2vis(w["x"]), w["mvis"]) < 1e-7
+    assert rel(p.vis2dirty(p.dirty2vis(w["x"]), w["wgt"]), w["hess"]) < 2e-7
+
+
+def test_fftconv_identities():
+    """HessianTree identities of test_hessian_tree.py:20-66 on the numpy restatement, and pcg."""
+    rng = np.random.default_rng(0)
+    nx = ny = 16
+    nxp = nyp = 32
+    x = rng.standard_normal((1, nx, ny))
+    one = [{"psfhat": np.ones((1, nxp, nyp // 2 + 1)), "beam": np.ones((1, nx, ny)), "wsum": np.ones(1)}]
+    np.testing.assert_allclose(fftconv.hessian_tree_dot(x, one, nxp, nyp), x, atol=1e-12)
+    np.testing.assert_allclose(fftconv.hessian_tree_dot(x, one, nxp, nyp, eta=0.5), 1.5 * x, atol=1e-12)
+    np.testing.assert_allclose(fftconv.hessian_tree_dot(x, one + one, nxp, nyp), x, atol=1e-12)
+    a = rng.standard_normal((3, 20, 20))
+    assert rel(fftconv.c2r(fftconv.r2c(a), 20), a) < 1e-14
+    d = 1.0 + rng.random((nx, ny))
+    sol = fftconv.pcg(lambda z: d * z, d * x[0], tol=1e-12, maxit=100, minit=1)
+    np.testing.assert_allclose(sol, x[0], atol=1e-8)
+
+
+@pytest.mark.parametrize("srf", [1.0, 2.0, 3.2])
+def test_counts_uniform_recount(srf):
+    """test_counts (test_weighting.py:47-118): uniform imaging weights make every occupied cell count 1."""
+    c = synth.make_case(3000, 4, 128, seed=4)
+    rng = np.random.default_rng(420)
+    cell = c["cell"] * 2.0 / srf
+    wgt = np.exp(rng.standard_normal((2,) + c["mask"].shape))
+    mask = np.ones_like(c["mask"])
+    nx = ny = 150
+    counts = ow.compute_counts(c["uvw"], c["freq"], mask, wgt, nx, ny, cell, cell, usign=1.0, vsign=-1.0)
+    assert np.isclose(counts.sum(), wgt[:, ow.uvcell_index(c["uvw"], c["freq"], mask, nx, ny, cell, cell) >= 0].sum())
+    imwgt = ow.counts_to_weights(counts.copy(), c["uvw"], c["freq"], np.ones_like(wgt), mask, nx, ny, cell, cell, -3,
+                                 usign=1.0, vsign=-1.0)
+    counts2 = ow.compute_counts(c["uvw"], c["freq"], mask, wgt * imwgt, nx, ny, cell, cell, usign=1.0, vsign=-1.0)
+    assert np.allclose(counts2[counts2 > 0], 1.0, rtol=1e-8, atol=1e-8)
+
+
+def test_uv2xy_golden(golden_dir):
+    """test_uv2xy (test_weighting.py:121-137) on the committed vectors, numpy formula and C index map."""
+    gold = np.load(f"{golden_dir}/uv2xy.npz")
+    for key in gold.files:
+        _, nx, cellx = key.split("_")
+        nx, cellx = int(nx), float(cellx)
+        u = gold[key]
+        ucell = 1.0 / (nx * cellx)
+        umax = np.abs(1 / cellx / 2)
+        assert ((np.floor((u + umax) / ucell) - np.arange(nx)) == 0).all()
+        uvw = np.stack([u, np.full(nx, 0.25 / cellx), np.zeros(nx)], axis=1)
+        cell = ow.uvcell_index(uvw, np.array([299792458.0]), np.ones((nx, 1), np.uint8), nx, 4, cellx, cellx, 1.0, 1.0)
+        assert np.array_equal(cell[:, 0] // 4, np.arange(nx))
+
+
+def test_kernel_table_and_poly():
+    tab = owg.kernel_table()
+    assert len(tab) == 15 * 13
+    for r in tab:
+        assert r["eps"] <= r["eps_max"] and 4 <= r["W"] <= 16
+    # errors decrease with W at fixed sigma until the double-precision floor
+    s2 = sorted((r for r in tab if r["sigma"] == 2.0), key=lambda r: r["W"])
+    assert all(a["eps"] > b["eps"] for a, b in zip(s2[:9], s2[1:10]))
+    W, beta = 12, next(r["beta"] for r in tab if r["W"] == 12 and r["sigma"] == 1.5)
+    kt = owg.kernel_poly_table(W, beta)
+    f = np.linspace(0, 1, 101)
+    for a in range(W):
+        x = (a + 1 - W / 2 - f) * 2 / W
+        exact = np.exp(beta * (np.sqrt(np.maximum(1 - x * x, 0)) - 1))
+        approx = np.polynomial.polynomial.polyval(2 * f - 1, kt[a])
+        assert np.abs(exact - approx).max() < 1e-11
+    assert owg.good_size(11468) == 11520 and owg.good_size(1025, True) == 1080
