@@ -178,7 +178,7 @@ def test_hess_tree_ray_pool_and_cg():
         np.testing.assert_allclose(got[b], loc, rtol=1e-12, atol=1e-13)
     abspsf = np.stack([p[0]["psfhat"][0] for p in ppb]) / wsum_tot
     beam = np.stack([p[0]["beam"][0] for p in ppb])
-    hp = HessPSF(nx, ny, abspsf, beam=beam, eta=etas)
+    hp = HessPSF(nx, ny, abspsf, beam=beam, eta=etas, taper_width=4)
     np.testing.assert_allclose(got, hp.dot(x).copy(), rtol=1e-10, atol=1e-12)
     sol = hr.cg(got, tol=1e-10, maxit=300, minit=1)
     assert rel(sol, x) < 1e-6
