@@ -42,8 +42,8 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
     b_vis = nactive * (2 * Sc + Sr + 2) + 2 * nrow * 24
     b_grid = P * (12 * G + 3 * I)
     per_launch = {
-        # one launch = one w-plane
-        "fft": 4 * G,                      # 1 read + 1 write per axis
+        # one launch = one w-plane (fft: one axis of one w-plane)
+        "fft": 2 * G,                      # 1 read + 1 write of the plane per axis
         "grid": G + nactive * (Sc + 24),   # plane written once + sorted vis value and (pu,pv,pw) record read
         "degrid": G + nactive * (Sc + 24),  # plane read once + record read, vis accumulator updated
         "pad_screen": G + I,               # image read, plane written

@@ -333,6 +333,168 @@ __global__ void k_crop_screen(ImgGeom g, const double2 *grid, int do_w, double w
 }
 
 // ---------------------------------------------------------------------------------------
+// pruned two-pass plane transform
+// ---------------------------------------------------------------------------------------
+// The 2-D FFT of a w-plane is done as two batched ROW transforms (rocFFT runs contiguous rows of
+// length <= 10240 at ~3.8 TB/s, strided columns at ~1 TB/s) with a transpose of our own in
+// between, and every pass is pruned to what the algorithm needs:
+//   A (nu, nv)  v contiguous : the uv-plane the scatter/gather kernels see.  Only the row blocks
+//                              that hold visibilities ("occupied", from the tile sort) are ever
+//                              cleared, transformed or transposed.
+//   B (ny, nu)  u contiguous : after the v-transform only the ny image columns are kept (crop)
+//                              and transposed; the u-transform then runs on ny rows.
+// The image accumulator of the plane loop is kept transposed (ny, nx).
+//   grid side  : clear occ(A) -> scatter -> FFT_v(occ rows) -> A2B (crop+transpose) -> FFT_u(ny rows)
+//                -> crop+screen+accumulate (B -> accT)
+//   degrid side: pad+screen (imgT -> B) -> FFT_u(ny rows) -> B2A (transpose+pad, occ rows) -> FFT_v(occ rows)
+//                -> gather
+
+constexpr int TP = 32;  // transpose tile
+
+// out (nc, nr) = in (nr, nc)^T [* mul (nr, nc)] [* mul2]   (real images)
+__global__ void k_transpose_f64(const double *in, const double *mul, const double *mul2, int nr, int nc, double *out)
+{
+    __shared__ double t[TP][TP + 1];
+    int c0 = blockIdx.x * TP, r0 = blockIdx.y * TP;
+    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+        int r = r0 + k, c = c0 + threadIdx.x;
+        if (r < nr && c < nc) {
+            size_t o = size_t(r) * nc + c;
+            double v = in[o];
+            if (mul) v *= mul[o];
+            if (mul2) v *= mul2[o];
+            t[k][threadIdx.x] = v;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+        int c = c0 + k, r = r0 + threadIdx.x;
+        if (r < nr && c < nc) out[size_t(c) * nr + r] = t[threadIdx.x][k];
+    }
+}
+
+// out (nx, ny) = accT (ny, nx)^T * corr [* beam] * scale + eta * x     (finalize with transposed accumulator)
+__global__ void k_finalize_T(const double *accT, const double *corr, const double *beam, double scale, double eta,
+                             const double *x, int nx, int ny, double *out)
+{
+    __shared__ double t[TP][TP + 1];
+    int x0 = blockIdx.x * TP, y0 = blockIdx.y * TP;  // accT row = y, col = x
+    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+        int y = y0 + k, xx = x0 + threadIdx.x;
+        if (y < ny && xx < nx) t[k][threadIdx.x] = accT[size_t(y) * nx + xx];
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+        int xx = x0 + k, y = y0 + threadIdx.x;
+        if (y < ny && xx < nx) {
+            size_t o = size_t(xx) * ny + y;
+            double v = t[threadIdx.x][k] * corr[o];
+            if (beam) v *= beam[o];
+            v *= scale;
+            if (x) v += eta * x[o];
+            out[o] = v;
+        }
+    }
+}
+
+// B (ny, nu) <- A (nu, nv): B[y][u] = A[u][wrap(y - ny/2, nv)] for occupied 32-row blocks of u, 0 elsewhere
+__global__ void k_a2b(ImgGeom g, const uint8_t *occ, const double2 *A, double2 *B)
+{
+    __shared__ double2 t[TP][TP + 1];
+    const int u0 = blockIdx.x * TP, y0 = blockIdx.y * TP;
+    const int hy = g.ny / 2;
+    const bool on = occ[blockIdx.x] != 0;
+    if (on) {
+        for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+            int u = u0 + k, y = y0 + threadIdx.x;
+            if (u < g.nu && y < g.ny) {
+                int v = y - hy;
+                if (v < 0) v += g.nv;
+                t[k][threadIdx.x] = A[size_t(u) * g.nv + v];
+            }
+        }
+        __syncthreads();
+    }
+    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+        int y = y0 + k, u = u0 + threadIdx.x;
+        if (u < g.nu && y < g.ny) B[size_t(y) * g.nu + u] = on ? t[threadIdx.x][k] : make_double2(0.0, 0.0);
+    }
+}
+
+// A (nu, nv) <- B (ny, nu) for occupied 32-row blocks of u: A[u][v] = B[y(v)][u], 0 where v is outside the image
+__global__ void k_b2a(ImgGeom g, const uint8_t *occ, const double2 *B, double2 *A)
+{
+    __shared__ double2 t[TP][TP + 1];
+    if (!occ[blockIdx.x]) return;
+    const int u0 = blockIdx.x * TP, v0 = blockIdx.y * TP;
+    const int hy = g.ny / 2;
+    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+        int v = v0 + k, u = u0 + threadIdx.x;
+        int y = -1;
+        if (v < g.ny - hy) y = v + hy;
+        else if (v >= g.nv - hy) y = v - (g.nv - hy);
+        double2 val = make_double2(0.0, 0.0);
+        if (y >= 0 && u < g.nu && v < g.nv) val = B[size_t(y) * g.nu + u];
+        t[k][threadIdx.x] = val;
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+        int u = u0 + k, v = v0 + threadIdx.x;
+        if (u < g.nu && v < g.nv) A[size_t(u) * g.nv + v] = t[threadIdx.x][k];
+    }
+}
+
+// degrid side: B[y][wrap(x - nx/2, nu)] = dcT[y][x] * exp(+2 pi i w_p t), 0 elsewhere (whole B written once)
+__global__ void k_pad_screen_T(ImgGeom g, const double *dcT, int do_w, double wplane, double2 *B)
+{
+    int u = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (u >= g.nu) return;
+    const int hx = g.nx / 2;
+    int ix = -1;
+    if (u < g.nx - hx) ix = u + hx;
+    else if (u >= g.nu - hx) ix = u - (g.nu - hx);
+    double2 out = make_double2(0.0, 0.0);
+    if (ix >= 0) {
+        double val = dcT[size_t(y) * g.nx + ix];
+        if (do_w) {
+            double ph = wplane * pixel_t(g, ix, y);
+            ph -= rint(ph);
+            double s, c;
+            sincospi(2.0 * ph, &s, &c);
+            out.x = val * c;
+            out.y = val * s;
+        } else {
+            out.x = val;
+        }
+    }
+    B[size_t(y) * g.nu + u] = out;
+}
+
+// grid side: accT[y][x] (+)= Re( B[y][wrap(x - nx/2, nu)] * exp(-2 pi i w_p t) )
+__global__ void k_crop_screen_T(ImgGeom g, const double2 *B, int do_w, double wplane, int first, double *accT)
+{
+    int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (ix >= g.nx) return;
+    int u = ix - g.nx / 2;
+    if (u < 0) u += g.nu;
+    double2 v = B[size_t(y) * g.nu + u];
+    double r;
+    if (do_w) {
+        double ph = wplane * pixel_t(g, ix, y);
+        ph -= rint(ph);
+        double s, c;
+        sincospi(2.0 * ph, &s, &c);
+        r = v.x * c + v.y * s;
+    } else {
+        r = v.x;
+    }
+    size_t o = size_t(y) * g.nx + ix;
+    accT[o] = first ? r : accT[o] + r;
+}
+
+// ---------------------------------------------------------------------------------------
 // the handle
 // ---------------------------------------------------------------------------------------
 
@@ -415,8 +577,17 @@ struct pfbhip_gridder {
     DevBuf<double2> d_grid, d_sval, d_sacc, d_vis;
     DevBuf<double> d_wgt, d_swgt, d_acc, d_img, d_img2, d_beam;
     DevBuf<char> d_fftwork;
+    DevBuf<double2> d_gridB;  // (ny, nu) transposed / cropped plane
+    DevBuf<double> d_accT;    // (ny, nx) transposed image accumulator / transposed degrid input
+    DevBuf<uint8_t> d_occ;    // occupancy of 32-row blocks of the uv-plane
     bool weights_bound = false;
-    rocfft_plan fft_fwd = nullptr, fft_bwd = nullptr;
+    struct RowSpan {
+        int64_t row0, nrows;                      // occupied rows [row0, row0 + nrows) of A
+        rocfft_plan fwd = nullptr, bwd = nullptr;  // batched length-nv row transforms
+    };
+    std::vector<RowSpan> spans;
+    int64_t occ_rows = 0;
+    rocfft_plan fftB_fwd = nullptr, fftB_bwd = nullptr;  // ny rows of length nu
     rocfft_execution_info fft_info = nullptr;
     StageTimer timer;
     std::vector<double> wplanes;  // w of every plane (wavelengths)
@@ -424,8 +595,12 @@ struct pfbhip_gridder {
 
     ~pfbhip_gridder()
     {
-        if (fft_fwd) rocfft_plan_destroy(fft_fwd);
-        if (fft_bwd) rocfft_plan_destroy(fft_bwd);
+        for (auto &sp : spans) {
+            if (sp.fwd) rocfft_plan_destroy(sp.fwd);
+            if (sp.bwd) rocfft_plan_destroy(sp.bwd);
+        }
+        if (fftB_fwd) rocfft_plan_destroy(fftB_fwd);
+        if (fftB_bwd) rocfft_plan_destroy(fftB_bwd);
         if (fft_info) rocfft_execution_info_destroy(fft_info);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -435,7 +610,8 @@ struct pfbhip_gridder {
         return d_uvw.bytes() + d_fc.bytes() + d_pu.bytes() + d_pv.bytes() + d_pw.bytes() + d_corr.bytes() +
                d_cfu.bytes() + d_cfv.bytes() + d_cheb.bytes() + d_ktab.bytes() + d_mask.bytes() + d_src.bytes() + d_work.bytes() +
                d_grid.bytes() + d_sval.bytes() + d_sacc.bytes() + d_vis.bytes() + d_wgt.bytes() + d_swgt.bytes() +
-               d_acc.bytes() + d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes();
+               d_acc.bytes() + d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes() + d_gridB.bytes() +
+               d_accT.bytes() + d_occ.bytes();
     }
 
     PlaneArgs plane_args(int plane) const
@@ -459,11 +635,22 @@ struct pfbhip_gridder {
         return a;
     }
 
-    void fft(bool forward)
+    // batched row transforms of the occupied rows of A (length nv)
+    void fft_rows_A(bool forward)
     {
-        void *buf[1] = {d_grid.p};
         timer.begin(2);
-        PFB_ROCFFT(rocfft_execute(forward ? fft_fwd : fft_bwd, buf, nullptr, fft_info));
+        for (auto &sp : spans) {
+            void *buf[1] = {d_grid.p + size_t(sp.row0) * size_t(info.nv)};
+            PFB_ROCFFT(rocfft_execute(forward ? sp.fwd : sp.bwd, buf, nullptr, fft_info));
+        }
+        timer.end();
+    }
+    // ny row transforms of B (length nu)
+    void fft_rows_B(bool forward)
+    {
+        void *buf[1] = {d_gridB.p};
+        timer.begin(2);
+        PFB_ROCFFT(rocfft_execute(forward ? fftB_fwd : fftB_bwd, buf, nullptr, fft_info));
         timer.end();
     }
 
@@ -507,45 +694,77 @@ struct pfbhip_gridder {
         default: throw std::runtime_error("unsupported kernel support"); \
     }
 
-    // sval (tile-sorted, weighted) -> acc image (raw, before correction)
-    void grid_all_planes(const double2 *sval, double *acc)
+    dim3 tgrid(int64_t ncols, int64_t nrows) const { return dim3(uint32_t(ceil_div(ncols, TP)), uint32_t(ceil_div(nrows, TP))); }
+
+    // sval (tile-sorted, weighted) -> accT, the TRANSPOSED (ny, nx) raw image (before correction)
+    void grid_all_planes(const double2 *sval)
     {
         const int64_t npix = int64_t(prm.nx) * prm.ny;
         if (info.nactive == 0 || info.nwork == 0) {
-            PFB_HIP(hipMemsetAsync(acc, 0, npix * sizeof(double), stream));
+            PFB_HIP(hipMemsetAsync(d_accT.p, 0, npix * sizeof(double), stream));
             return;
         }
         for (int p = 0; p < info.nplanes; ++p) {
             timer.begin(5);
-            PFB_HIP(hipMemsetAsync(d_grid.p, 0, d_grid.bytes(), stream));
+            for (auto &sp : spans)
+                PFB_HIP(hipMemsetAsync(d_grid.p + size_t(sp.row0) * size_t(info.nv), 0,
+                                       size_t(sp.nrows) * size_t(info.nv) * sizeof(double2), stream));
             timer.end();
             timer.begin(0);
             PFB_W_DISPATCH(launch_grid_w, p, sval);
             PFB_HIP(hipGetLastError());
             timer.end();
-            fft(false);
+            fft_rows_A(false);
             timer.begin(4);
-            dim3 blk(256), grd(uint32_t(ceil_div(prm.ny, 256)), uint32_t(prm.nx));
-            hipLaunchKernelGGL(k_crop_screen, grd, blk, 0, stream, geom, d_grid.p, prm.do_wgridding,
-                               wplanes[size_t(p)], p == 0 ? 1 : 0, acc);
+            hipLaunchKernelGGL(k_a2b, tgrid(info.nu, prm.ny), dim3(TP, 8), 0, stream, geom, d_occ.p, d_grid.p, d_gridB.p);
+            PFB_HIP(hipGetLastError());
+            timer.end();
+            fft_rows_B(false);
+            timer.begin(4);
+            hipLaunchKernelGGL(k_crop_screen_T, dim3(uint32_t(ceil_div(prm.nx, 256)), uint32_t(prm.ny)), dim3(256), 0,
+                               stream, geom, d_gridB.p, prm.do_wgridding, wplanes[size_t(p)], p == 0 ? 1 : 0, d_accT.p);
             PFB_HIP(hipGetLastError());
             timer.end();
         }
     }
 
-    // dc image (already multiplied by the correction) -> sacc (tile-sorted)
-    void degrid_all_planes(const double *dc, double2 *sacc)
+    // out = accT^T * corr [* beam] * scale + eta * x
+    void finalize(const double *beam, double scale, double eta, const double *x, double *out)
+    {
+        timer.begin(5);
+        hipLaunchKernelGGL(k_finalize_T, tgrid(prm.nx, prm.ny), dim3(TP, 8), 0, stream, d_accT.p, d_corr.p, beam, scale,
+                           eta, x, int(prm.nx), int(prm.ny), out);
+        PFB_HIP(hipGetLastError());
+        timer.end();
+    }
+
+    // accT = (x * corr [* beam])^T : the degrid input in the transposed layout
+    void prepare_degrid_input(const double *x, const double *beam)
+    {
+        timer.begin(5);
+        hipLaunchKernelGGL(k_transpose_f64, tgrid(prm.ny, prm.nx), dim3(TP, 8), 0, stream, x, d_corr.p, beam, int(prm.nx),
+                           int(prm.ny), d_accT.p);
+        PFB_HIP(hipGetLastError());
+        timer.end();
+    }
+
+    // accT (transposed, corrected image) -> sacc (tile-sorted)
+    void degrid_all_planes(double2 *sacc)
     {
         PFB_HIP(hipMemsetAsync(sacc, 0, size_t(std::max<int64_t>(info.nactive, 1)) * sizeof(double2), stream));
         if (info.nactive == 0 || info.nwork == 0) return;
         for (int p = 0; p < info.nplanes; ++p) {
             timer.begin(3);
-            dim3 blk(256), grd(uint32_t(ceil_div(info.nv, 256)), uint32_t(info.nu));
-            hipLaunchKernelGGL(k_pad_screen, grd, blk, 0, stream, geom, dc, prm.do_wgridding,
-                               wplanes[size_t(p)], d_grid.p);
+            hipLaunchKernelGGL(k_pad_screen_T, dim3(uint32_t(ceil_div(info.nu, 256)), uint32_t(prm.ny)), dim3(256), 0,
+                               stream, geom, d_accT.p, prm.do_wgridding, wplanes[size_t(p)], d_gridB.p);
             PFB_HIP(hipGetLastError());
             timer.end();
-            fft(true);
+            fft_rows_B(true);
+            timer.begin(3);
+            hipLaunchKernelGGL(k_b2a, tgrid(info.nu, info.nv), dim3(TP, 8), 0, stream, geom, d_occ.p, d_gridB.p, d_grid.p);
+            PFB_HIP(hipGetLastError());
+            timer.end();
+            fft_rows_A(true);
             timer.begin(1);
             PFB_W_DISPATCH(launch_degrid_w, p, sacc);
             PFB_HIP(hipGetLastError());
@@ -888,27 +1107,74 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
 
     // ---- scratch + FFT plans ----
     g->d_grid.alloc(size_t(info.nu) * size_t(info.nv));
-    g->d_acc.alloc(size_t(npix));
     g->d_img.alloc(size_t(npix));
     g->d_sval.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
     g->d_sacc.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
 
+    g->d_gridB.alloc(size_t(prm.ny) * size_t(info.nu));
+    g->d_accT.alloc(size_t(npix));
+
+    // occupancy of 32-row blocks of the uv-plane: tile rows that hold work, plus the block their
+    // (W-1)-cell halo spills into
+    const int64_t nblk = ceil_div(info.nu, TP);
+    std::vector<uint8_t> occ(size_t(nblk), 0);
+    static_assert(TP == TILE, "row-block occupancy assumes transpose tile == uv tile");
+    for (const WorkItem &wi : work) {
+        int64_t tu = wi.tile / uint32_t(m.ntv);
+        occ[size_t(tu)] = 1;
+        int64_t last_row = (tu * TILE + TILE + info.W - 2) % info.nu;  // last cell row the tile's footprint can touch
+        occ[size_t(last_row / TP)] = 1;
+        if (tu * TILE + TILE + info.W - 2 >= info.nu) occ[0] = 1;
+    }
+    // spans of consecutive occupied blocks (at most a handful for a centrally concentrated uv coverage)
+    std::vector<std::pair<int64_t, int64_t>> runs;
+    for (int64_t bk = 0; bk < nblk;) {
+        if (!occ[size_t(bk)]) { ++bk; continue; }
+        int64_t e = bk;
+        while (e < nblk && occ[size_t(e)]) ++e;
+        runs.emplace_back(bk, e);
+        bk = e;
+    }
+    if (runs.size() > 4) {  // fragmented coverage: transform everything
+        std::fill(occ.begin(), occ.end(), uint8_t(1));
+        runs.assign(1, {0, nblk});
+    }
+    g->d_occ.alloc(size_t(nblk));
+    PFB_HIP(hipMemcpyAsync(g->d_occ.p, occ.data(), occ.size(), hipMemcpyHostToDevice, st));
+
     rocfft_setup_once();
-    size_t lengths[2] = {size_t(info.nv), size_t(info.nu)};  // fastest first
-    PFB_ROCFFT(rocfft_plan_create(&g->fft_fwd, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
-                                  rocfft_precision_double, 2, lengths, 1, nullptr));
-    PFB_ROCFFT(rocfft_plan_create(&g->fft_bwd, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
-                                  rocfft_precision_double, 2, lengths, 1, nullptr));
-    size_t wf = 0, wb = 0;
-    PFB_ROCFFT(rocfft_plan_get_work_buffer_size(g->fft_fwd, &wf));
-    PFB_ROCFFT(rocfft_plan_get_work_buffer_size(g->fft_bwd, &wb));
+    size_t wmax = 0;
+    auto make_rows = [&](int64_t len, int64_t batch, bool forward) {
+        rocfft_plan pl = nullptr;
+        size_t lengths[1] = {size_t(len)};
+        PFB_ROCFFT(rocfft_plan_create(&pl, rocfft_placement_inplace,
+                                      forward ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
+                                      rocfft_precision_double, 1, lengths, size_t(batch), nullptr));
+        size_t w = 0;
+        PFB_ROCFFT(rocfft_plan_get_work_buffer_size(pl, &w));
+        wmax = std::max(wmax, w);
+        return pl;
+    };
+    g->occ_rows = 0;
+    for (auto &r : runs) {
+        pfbhip_gridder::RowSpan sp;
+        sp.row0 = r.first * TP;
+        sp.nrows = std::min<int64_t>(r.second * TP, info.nu) - sp.row0;
+        sp.fwd = make_rows(info.nv, sp.nrows, true);
+        sp.bwd = make_rows(info.nv, sp.nrows, false);
+        g->occ_rows += sp.nrows;
+        g->spans.push_back(sp);
+    }
+    g->fftB_fwd = make_rows(info.nu, prm.ny, true);
+    g->fftB_bwd = make_rows(info.nu, prm.ny, false);
     PFB_ROCFFT(rocfft_execution_info_create(&g->fft_info));
-    size_t wmax = std::max(wf, wb);
     if (wmax) {
         g->d_fftwork.alloc(wmax);
         PFB_ROCFFT(rocfft_execution_info_set_work_buffer(g->fft_info, g->d_fftwork.p, wmax));
     }
     PFB_ROCFFT(rocfft_execution_info_set_stream(g->fft_info, st));
+    // rows of A outside the occupied spans are never written: clear the plane once
+    PFB_HIP(hipMemsetAsync(g->d_grid.p, 0, g->d_grid.bytes(), st));
     PFB_HIP(hipStreamSynchronize(st));
     info.device_bytes = g->device_bytes();
 }
@@ -992,10 +1258,8 @@ int pfbhip_gridder_vis2dirty(pfbhip_gridder *g, const double *vis_host, const do
                                g->info.nactive, g->d_vis.p, wgt_host ? g->d_wgt.p : nullptr, int(g->shifting),
                                g->info.lshift, g->info.mshift, g->info.nshift, g->d_sval.p);
         PFB_HIP(hipGetLastError());
-        g->grid_all_planes(g->d_sval.p, g->d_acc.p);
-        hipLaunchKernelGGL(k_finalize, blocks1d(npix), dim3(256), 0, st, npix, g->d_acc.p, g->d_corr.p,
-                           (const double *)nullptr, 1.0, 0.0, (const double *)nullptr, g->d_img.p);
-        PFB_HIP(hipGetLastError());
+        g->grid_all_planes(g->d_sval.p);
+        g->finalize(nullptr, 1.0, 0.0, nullptr, g->d_img.p);
         PFB_HIP(hipMemcpyAsync(dirty_host, g->d_img.p, size_t(npix) * sizeof(double), hipMemcpyDeviceToHost, st));
         PFB_HIP(hipStreamSynchronize(st));
     });
@@ -1038,10 +1302,8 @@ int pfbhip_gridder_dirty2vis(pfbhip_gridder *g, const double *dirty_host, const 
         const int64_t npix = g->prm.nx * g->prm.ny;
         PFB_HIP(hipMemcpyAsync(g->d_img.p, dirty_host, size_t(npix) * sizeof(double), hipMemcpyHostToDevice, st));
         g->upload_vis_wgt(nullptr, wgt_host);
-        hipLaunchKernelGGL(k_mul_images, blocks1d(npix), dim3(256), 0, st, npix, g->d_img.p, g->d_corr.p,
-                           (const double *)nullptr, g->d_acc.p);
-        PFB_HIP(hipGetLastError());
-        g->degrid_all_planes(g->d_acc.p, g->d_sacc.p);
+        g->prepare_degrid_input(g->d_img.p, nullptr);
+        g->degrid_all_planes(g->d_sacc.p);
         if (g->nvis) {
             g->d_vis.ensure(size_t(g->nvis));
             PFB_HIP(hipMemsetAsync(g->d_vis.p, 0, size_t(g->nvis) * sizeof(double2), st));
@@ -1078,23 +1340,17 @@ static void hessian_dev_impl(pfbhip_gridder *g, const double *x_dev, const doubl
     PFB_REQUIRE(g->weights_bound, "call pfbhip_gridder_set_weights before the Hessian");
     hipStream_t st = g->stream;
     const int64_t npix = g->prm.nx * g->prm.ny;
-    g->timer.begin(5);
-    hipLaunchKernelGGL(k_mul_images, blocks1d(npix), dim3(256), 0, st, npix, x_dev, g->d_corr.p, beam_dev, g->d_acc.p);
-    PFB_HIP(hipGetLastError());
-    g->timer.end();
-    g->degrid_all_planes(g->d_acc.p, g->d_sacc.p);
+    g->prepare_degrid_input(x_dev, beam_dev);
+    g->degrid_all_planes(g->d_sacc.p);
     g->timer.begin(5);
     if (g->info.nactive)
         hipLaunchKernelGGL(k_scale_sorted, blocks1d(g->info.nactive), dim3(256), 0, st, g->info.nactive, g->d_sacc.p,
                            g->d_swgt.p, g->d_sval.p);
     PFB_HIP(hipGetLastError());
     g->timer.end();
-    g->grid_all_planes(g->d_sval.p, g->d_acc.p);
-    g->timer.begin(5);
-    hipLaunchKernelGGL(k_finalize, blocks1d(npix), dim3(256), 0, st, npix, g->d_acc.p, g->d_corr.p, beam_dev,
-                       wsum > 0.0 ? 1.0 / wsum : 1.0, eta, eta != 0.0 ? x_dev : nullptr, out_dev);
-    PFB_HIP(hipGetLastError());
-    g->timer.end();
+    g->grid_all_planes(g->d_sval.p);
+    g->finalize(beam_dev, wsum > 0.0 ? 1.0 / wsum : 1.0, eta, eta != 0.0 ? x_dev : nullptr, out_dev);
+    (void)npix;
 }
 
 int pfbhip_gridder_hessian_dev(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta, double wsum,
@@ -1158,11 +1414,8 @@ int pfbhip_gridder_degrid_dev(pfbhip_gridder *g, const double *dirty_dev, double
 {
     return guarded([&] {
         PFB_REQUIRE(g && dirty_dev && vis_sorted_dev, "NULL argument");
-        const int64_t npix = g->prm.nx * g->prm.ny;
-        hipLaunchKernelGGL(k_mul_images, blocks1d(npix), dim3(256), 0, g->stream, npix, dirty_dev, g->d_corr.p,
-                           (const double *)nullptr, g->d_acc.p);
-        PFB_HIP(hipGetLastError());
-        g->degrid_all_planes(g->d_acc.p, reinterpret_cast<double2 *>(vis_sorted_dev));
+        g->prepare_degrid_input(dirty_dev, nullptr);
+        g->degrid_all_planes(reinterpret_cast<double2 *>(vis_sorted_dev));
         PFB_HIP(hipStreamSynchronize(g->stream));
     });
 }
@@ -1171,11 +1424,8 @@ int pfbhip_gridder_grid_dev(pfbhip_gridder *g, const double *vis_sorted_dev, dou
 {
     return guarded([&] {
         PFB_REQUIRE(g && dirty_dev && vis_sorted_dev, "NULL argument");
-        const int64_t npix = g->prm.nx * g->prm.ny;
-        g->grid_all_planes(reinterpret_cast<const double2 *>(vis_sorted_dev), g->d_acc.p);
-        hipLaunchKernelGGL(k_finalize, blocks1d(npix), dim3(256), 0, g->stream, npix, g->d_acc.p, g->d_corr.p,
-                           (const double *)nullptr, 1.0, 0.0, (const double *)nullptr, dirty_dev);
-        PFB_HIP(hipGetLastError());
+        g->grid_all_planes(reinterpret_cast<const double2 *>(vis_sorted_dev));
+        g->finalize(nullptr, 1.0, 0.0, nullptr, dirty_dev);
         PFB_HIP(hipStreamSynchronize(g->stream));
     });
 }
