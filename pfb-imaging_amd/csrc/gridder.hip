@@ -657,9 +657,9 @@ struct pfbhip_gridder {
     template <int W>
     static constexpr size_t lds_bytes()
     {
-        constexpr int L = TILE + W - 1, LS = (L & 1) ? L + 1 : L, D = kernel_poly_degree_c(W);
+        constexpr int D = kernel_poly_degree_c(W);
         static_assert(kernel_poly_degree_c(W) == kernel_poly_degree(W), "degree mismatch");
-        return (size_t(2) * L * LS + size_t(W) * (D + 1)) * sizeof(double);
+        return (size_t(2) * tile_rows(W) * tile_stride(W) + size_t(W) * (D + 1)) * sizeof(double);
     }
     template <int W>
     void launch_grid_w(int plane, const double2 *sval)

@@ -76,6 +76,14 @@ __device__ __forceinline__ double rotn_f64(double v)
 // the centre, so two XCDs got nearly all the work.)
 __device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t) { return b; }
 
+// LDS tile geometry shared by host (allocation) and device: rows of even stride; the branch-free
+// diagonal walk of wide kernels (W >= 14) may touch row/column T+15 with zero contributions.
+__host__ __device__ constexpr int tile_stride(int W)
+{
+    return W >= 14 ? TILE + 16 : (((TILE + W - 1) & 1) ? TILE + W : TILE + W - 1);
+}
+__host__ __device__ constexpr int tile_rows(int W) { return W >= 14 ? TILE + 16 : TILE + W - 1; }
+
 __device__ __forceinline__ int wrap_once(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
 template <int D>
@@ -122,8 +130,8 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid(PlaneArgs a, const double
 {
     constexpr int D = kernel_poly_degree_c(W);
     constexpr int L = TILE + W - 1;
-    constexpr int LS = (L & 1) ? L + 1 : L;  // even row stride: conflict-free diagonal walk
-    constexpr int LL = L * LS;
+    constexpr int LS = tile_stride(W);  // even row stride: conflict-free diagonal walk
+    constexpr int LL = tile_rows(W) * LS;
     extern __shared__ double lds[];
     double *lre = lds;
     double *lim = lds + LL;
@@ -146,37 +154,51 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid(PlaneArgs a, const double
     const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
     const double shift = 1.0 - 0.5 * double(W);
 
-    for (uint32_t base = wi.begin + wave * 64; base < wi.end; base += (GRID_THREADS / 64) * 64) {
-        const int nit = int(min(64u, wi.end - base) + 3u) >> 2;
-        for (int it = 0; it < nit; ++it) {
-            const uint32_t j = base + it * 4 + g;
-            const bool valid = j < wi.end;
-            const double pu = valid ? a.pu[j] : 0.0;
-            const double pv = valid ? a.pv[j] : 0.0;
-            const double pw = (valid && a.do_w) ? a.pw[j] : 0.0;
-            const double2 val = valid ? sval[j] : make_double2(0.0, 0.0);
+    // Records are streamed 4 visibilities (one per DPP row) at a time, one step ahead.
+    const uint32_t stride = (GRID_THREADS / 64) * 4;  // visibilities per workgroup step
+    uint32_t j = wi.begin + wave * 4 + g;
+    bool valid = j < wi.end;
+    double pu = valid ? a.pu[j] : 0.0, pv = valid ? a.pv[j] : 0.0, pw = (valid && a.do_w) ? a.pw[j] : 0.0;
+    double2 val = valid ? sval[j] : make_double2(0.0, 0.0);
+    for (uint32_t jb = wi.begin + wave * 4; jb < wi.end; jb += stride) {
+        // prefetch the next step's records
+        const uint32_t jn = j + stride;
+        const bool nvalid = jn < wi.end;
+        const double npu = nvalid ? a.pu[jn] : 0.0, npv = nvalid ? a.pv[jn] : 0.0;
+        const double npw = (nvalid && a.do_w) ? a.pw[jn] : 0.0;
+        const double2 nval = nvalid ? sval[jn] : make_double2(0.0, 0.0);
+        {
             double kw = plane_weight<W, D>(a, pw, wtab);
             if (!valid) kw = 0.0;
             const double fu = floor(pu + shift), fv = floor(pv + shift);
             const double zu = 2.0 * ((pu + shift) - fu) - 1.0, zv = 2.0 * ((pv + shift) - fv) - 1.0;
-            double ku = horner<D>(c, zu);
+            double ku = horner<D>(c, zu);  // 0 for lanes b >= W (zero coefficients)
             const double kv = horner<D>(c, zv) * kw;
             const int lu = wrap_once((int)fu, a.nu) - bu, lv = wrap_once((int)fv, a.nv) - bv;
             const double vr = val.x * kv, vi = val.y * kv;
-            const bool col_ok = (b < W) && (kw != 0.0);
             const int colbase = lu * LS + lv + b;
             int arow = b;
+            if (kw != 0.0) {  // rows that do not touch this plane (or are past the end) sit out
+                // Every lane adds at every step: taps outside the W x W footprint carry ku == 0 or
+                // kv == 0 and land in the padding rows/columns of the tile (LR rows are allocated).
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (col_ok && arow < W) {
+                for (int i = 0; i < 16; ++i) {
                     const int off = colbase + arow * LS;
-                    unsafeAtomicAdd(&lre[off], vr * ku);
-                    unsafeAtomicAdd(&lim[off], vi * ku);
+                    if (W >= 14 || (arow < W && b < W)) {
+                        unsafeAtomicAdd(&lre[off], vr * ku);
+                        unsafeAtomicAdd(&lim[off], vi * ku);
+                    }
+                    ku = rot1_f64(ku);
+                    arow = rot1_i32(arow);
                 }
-                ku = rot1_f64(ku);
-                arow = rot1_i32(arow);
             }
         }
+        j = jn;
+        valid = nvalid;
+        pu = npu;
+        pv = npv;
+        pw = npw;
+        val = nval;
     }
     __syncthreads();
     double *gp = reinterpret_cast<double *>(grid);
@@ -200,8 +222,8 @@ __global__ void __launch_bounds__(GRID_THREADS) k_degrid(PlaneArgs a, const doub
 {
     constexpr int D = kernel_poly_degree_c(W);
     constexpr int L = TILE + W - 1;
-    constexpr int LS = (L & 1) ? L + 1 : L;
-    constexpr int LL = L * LS;
+    constexpr int LS = tile_stride(W);
+    constexpr int LL = tile_rows(W) * LS;
     extern __shared__ double lds[];
     double2 *tile = reinterpret_cast<double2 *>(lds);
     double *wtab = lds + 2 * LL;
@@ -218,6 +240,11 @@ __global__ void __launch_bounds__(GRID_THREADS) k_degrid(PlaneArgs a, const doub
         gv = gv >= a.nv ? gv % a.nv : gv;
         tile[la * LS + lb] = grid[size_t(gu) * size_t(a.nv) + size_t(gv)];
     }
+    if (W >= 14)  // padding cells are read (and multiplied by 0): keep them finite
+        for (int i = threadIdx.x; i < LL; i += GRID_THREADS) {
+            const int la = i / LS, lb = i - la * LS;
+            if (la >= L || lb >= L) tile[i] = make_double2(0.0, 0.0);
+        }
     for (int i = threadIdx.x; i < W * (D + 1); i += GRID_THREADS) wtab[i] = a.ktab[i];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -229,14 +256,16 @@ __global__ void __launch_bounds__(GRID_THREADS) k_degrid(PlaneArgs a, const doub
 
     const double shift = 1.0 - 0.5 * double(W);
 
-    for (uint32_t base = wi.begin + wave * 64; base < wi.end; base += (GRID_THREADS / 64) * 64) {
-        const int nit = int(min(64u, wi.end - base) + 3u) >> 2;
-        for (int it = 0; it < nit; ++it) {
-            const uint32_t j = base + it * 4 + g;
-            const bool valid = j < wi.end;
-            const double pu = valid ? a.pu[j] : 0.0;
-            const double pv = valid ? a.pv[j] : 0.0;
-            const double pw = (valid && a.do_w) ? a.pw[j] : 0.0;
+    const uint32_t stride = (GRID_THREADS / 64) * 4;
+    uint32_t j = wi.begin + wave * 4 + g;
+    bool valid = j < wi.end;
+    double pu = valid ? a.pu[j] : 0.0, pv = valid ? a.pv[j] : 0.0, pw = (valid && a.do_w) ? a.pw[j] : 0.0;
+    for (uint32_t jb = wi.begin + wave * 4; jb < wi.end; jb += stride) {
+        const uint32_t jn = j + stride;
+        const bool nvalid = jn < wi.end;
+        const double npu = nvalid ? a.pu[jn] : 0.0, npv = nvalid ? a.pv[jn] : 0.0;
+        const double npw = (nvalid && a.do_w) ? a.pw[jn] : 0.0;
+        {
             double kw = plane_weight<W, D>(a, pw, wtab);
             if (!valid) kw = 0.0;
             const double fu = floor(pu + shift), fv = floor(pv + shift);
@@ -244,19 +273,20 @@ __global__ void __launch_bounds__(GRID_THREADS) k_degrid(PlaneArgs a, const doub
             double ku = horner<D>(c, zu);
             const double kv = horner<D>(c, zv) * kw;
             const int lu = wrap_once((int)fu, a.nu) - bu, lv = wrap_once((int)fv, a.nv) - bv;
-            const bool col_ok = (b < W) && (kw != 0.0);
             const int colbase = lu * LS + lv + b;
             int arow = b;
             double sr = 0.0, si = 0.0;
+            if (kw != 0.0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (col_ok && arow < W) {
-                    const double2 gval = tile[colbase + arow * LS];
-                    sr = fma(gval.x, ku, sr);
-                    si = fma(gval.y, ku, si);
+                for (int i = 0; i < 16; ++i) {
+                    if (W >= 14 || (arow < W && b < W)) {
+                        const double2 gval = tile[colbase + arow * LS];
+                        sr = fma(gval.x, ku, sr);
+                        si = fma(gval.y, ku, si);
+                    }
+                    ku = rot1_f64(ku);
+                    arow = rot1_i32(arow);
                 }
-                ku = rot1_f64(ku);
-                arow = rot1_i32(arow);
             }
             sr *= kv;
             si *= kv;
@@ -268,13 +298,18 @@ __global__ void __launch_bounds__(GRID_THREADS) k_degrid(PlaneArgs a, const doub
             si += rotn_f64<2>(si);
             sr += rotn_f64<1>(sr);
             si += rotn_f64<1>(si);
-            if (b == 0 && valid && kw != 0.0) {
+            if (b == 0 && kw != 0.0) {
                 double2 acc = sacc[j];
                 acc.x += sr;
                 acc.y += si;
                 sacc[j] = acc;
             }
         }
+        j = jn;
+        valid = nvalid;
+        pu = npu;
+        pv = npv;
+        pw = npw;
     }
 }
 
