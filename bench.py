@@ -57,6 +57,17 @@ def cpu_baseline(case, ginfo, oracle_params, nplanes_sample=2):
     from oracle import _lib as olib
     from oracle import wgridder as owg
 
+    # threads = this process's CPU share (cgroup quota / affinity), not the host's core count
+    nthr = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            nthr = min(nthr, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    nthr = int(os.environ.get("PFB_CPU_THREADS", min(nthr, 16)))
+    olib.lib().pfbo_set_num_threads(nthr)
+    owg.FFT_WORKERS = nthr
     c = case
     t0 = time.time()
     plan = owg.Plan(c["uvw"], c["freq"], c["mask"], c["nx"], c["ny"], c["cell"], c["cell"], 0.0, 0.0, 1e-7, False,
@@ -115,9 +126,11 @@ def main():
         wl = f"{args.config}: 1 band/GPU, {synth.CONFIGS[args.config][0]}x{synth.CONFIGS[args.config][1]} vis, " \
              f"{synth.CONFIGS[args.config][2]}^2 image, exact Hessian apply (degrid+FFT+grid), double precision"
     else:
-        nrow, nchan, npix = (int(v) for v in args.config.split(","))
-        case = synth.make_case(nrow, nchan, npix, seed=rank)
-        wl = f"custom {nrow}x{nchan} vis, {npix}^2 image"
+        parts = args.config.split(",")
+        nrow, nchan, npix = (int(v) for v in parts[:3])
+        zscale = float(parts[3]) if len(parts) > 3 else 1e-3
+        case = synth.make_case(nrow, nchan, npix, zscale=zscale, seed=rank)
+        wl = f"custom {nrow}x{nchan} vis, {npix}^2 image, antenna z-scale {zscale}"
     nx, ny = case["nx"], case["ny"]
     t0 = time.time()
     g = Gridder(case["uvw"], case["freq"], case["mask"], npix_x=nx, npix_y=ny, pixsize_x=case["cell"],
@@ -183,7 +196,7 @@ def main():
             "data": "synthetic",
             "hessian_applies_per_s": world / (elapsed / args.steps),
             "config": {
-                "workload": wl, "bands": world, "vis_per_band": int(case["uvw"].shape[0] * case["freq"].size),
+                "workload": wl, "bands": world, "w_scheme": "polynomial planes" if info["wmode"] == 1 else "ES-kernel planes", "vis_per_band": int(case["uvw"].shape[0] * case["freq"].size),
                 "active_vis_per_band": int(g.nactive), "image": [nx, ny], "epsilon": args.epsilon,
                 "grid": [info["nu"], info["nv"]], "w_planes": info["nplanes"], "kernel_support": info["W"],
                 "sigma": info["sigma"], "parallelism": f"band-per-gpu x{world}" + (" + RCCL reduce" if world > 1 else ""),

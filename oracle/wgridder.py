@@ -37,6 +37,7 @@ SPEED_OF_LIGHT = 299792458.0
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _TABLE = None
 TILE = 32
+FFT_WORKERS = -1  # scipy.fft workers (-1 = all cores); bench sets it to its CPU share
 
 
 def good_size(n, real=False):
@@ -380,11 +381,11 @@ class Plan:
         p = self.p
         grid = np.zeros((p.nu, p.nv), dtype=np.complex128)
         grid[np.ix_(self.xi, self.yi)] = dc * self._screen(plane, +1.0) if self.do_w else dc
-        grid = sfft.fft2(grid, workers=-1, overwrite_x=True)
+        grid = sfft.fft2(grid, workers=FFT_WORKERS, overwrite_x=True)
         self._degrid(grid, plane, sacc)
         sval = sacc * swgt_flat
         grid = self.grid_plane(sval, plane)
-        img = sfft.ifft2(grid, norm="forward", workers=-1, overwrite_x=True)
+        img = sfft.ifft2(grid, norm="forward", workers=FFT_WORKERS, overwrite_x=True)
         sub = img[np.ix_(self.xi, self.yi)]
         if self.do_w:
             sub *= self._screen(plane, -1.0)
@@ -462,7 +463,7 @@ class Plan:
         acc = np.zeros((self.nx, self.ny), dtype=np.float64)
         for plane in range(p.nplanes):
             grid = self.grid_plane(sval, plane)
-            img = sfft.ifft2(grid, norm="forward", workers=-1, overwrite_x=True)
+            img = sfft.ifft2(grid, norm="forward", workers=FFT_WORKERS, overwrite_x=True)
             sub = img[np.ix_(self.xi, self.yi)]
             if self.do_w:
                 sub *= self._screen(plane, -1.0)
@@ -477,7 +478,7 @@ class Plan:
         for plane in range(p.nplanes):
             grid = np.zeros((p.nu, p.nv), dtype=np.complex128)
             grid[np.ix_(self.xi, self.yi)] = dc * self._screen(plane, +1.0) if self.do_w else dc
-            grid = sfft.fft2(grid, workers=-1, overwrite_x=True)
+            grid = sfft.fft2(grid, workers=FFT_WORKERS, overwrite_x=True)
             self._degrid(grid, plane, acc)
         if self.phase is not None:
             acc *= np.conj(self.phase)

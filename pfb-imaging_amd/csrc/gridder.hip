@@ -29,6 +29,7 @@
 #include "devcg.hpp"
 #include "eskernel.hpp"
 #include "gridder_kernels.hpp"
+#include "gridder_kernels_mp.hpp"
 #include "vismap.hpp"
 
 namespace pfbhip {
@@ -587,6 +588,8 @@ struct pfbhip_gridder {
     };
     std::vector<RowSpan> spans;
     int64_t occ_rows = 0;
+    int kp_max = 1;              // planes scattered / gathered per pass (LDS holds kp_max tiles)
+    size_t plane_stride = 0;     // complex elements per plane of d_grid
     rocfft_plan fftB_fwd = nullptr, fftB_bwd = nullptr;  // ny rows of length nu
     rocfft_execution_info fft_info = nullptr;
     StageTimer timer;
@@ -636,11 +639,11 @@ struct pfbhip_gridder {
     }
 
     // batched row transforms of the occupied rows of A (length nv)
-    void fft_rows_A(bool forward)
+    void fft_rows_A(bool forward, int k = 0)
     {
         timer.begin(2);
         for (auto &sp : spans) {
-            void *buf[1] = {d_grid.p + size_t(sp.row0) * size_t(info.nv)};
+            void *buf[1] = {d_grid.p + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv)};
             PFB_ROCFFT(rocfft_execute(forward ? sp.fwd : sp.bwd, buf, nullptr, fft_info));
         }
         timer.end();
@@ -676,6 +679,46 @@ struct pfbhip_gridder {
         hipLaunchKernelGGL(k_degrid<W>, dim3(nblk), dim3(GRID_THREADS), lds, stream, plane_args(plane), d_grid.p,
                            sacc);
     }
+    GroupArgs group_args(int plane0, int kp) const
+    {
+        GroupArgs ga;
+        ga.a = plane_args(plane0);
+        ga.kp = kp;
+        for (int k = 0; k < KP_MAX; ++k)
+            ga.coefk[k] = (info.wmode == 1 && k < kp) ? lagr_coef[size_t(plane0 + k)] : 1.0;
+        ga.plane_stride = plane_stride;
+        return ga;
+    }
+    template <int W>
+    static constexpr size_t lds_bytes_mp()
+    {
+        constexpr int D = kernel_poly_degree_c(W);
+        return (size_t(2) * KP_MAX * tile_rows(W) * tile_stride(W) + size_t(W) * (D + 1)) * sizeof(double);
+    }
+    template <int W>
+    void launch_grid_mp_w(int plane0, int kp, const double2 *sval)
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_mp<W>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp<W>())));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_grid_mp<W>, dim3(uint32_t(info.nwork)), dim3(MP_THREADS), lds_bytes_mp<W>(), stream,
+                           group_args(plane0, kp), sval, d_grid.p);
+    }
+    template <int W>
+    void launch_degrid_mp_w(int plane0, int kp, double2 *sacc)
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_degrid_mp<W>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp<W>())));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_degrid_mp<W>, dim3(uint32_t(info.nwork)), dim3(MP_THREADS), lds_bytes_mp<W>(), stream,
+                           group_args(plane0, kp), d_grid.p, sacc);
+    }
 #define PFB_W_DISPATCH(fn, ...)                                          \
     switch (info.W) {                                                    \
         case 4: fn<4>(__VA_ARGS__); break;                               \
@@ -704,27 +747,38 @@ struct pfbhip_gridder {
             PFB_HIP(hipMemsetAsync(d_accT.p, 0, npix * sizeof(double), stream));
             return;
         }
-        for (int p = 0; p < info.nplanes; ++p) {
+        for (int p0 = 0; p0 < info.nplanes; p0 += kp_max) {
+            const int kp = int(std::min<int64_t>(kp_max, info.nplanes - p0));
             timer.begin(5);
-            for (auto &sp : spans)
-                PFB_HIP(hipMemsetAsync(d_grid.p + size_t(sp.row0) * size_t(info.nv), 0,
-                                       size_t(sp.nrows) * size_t(info.nv) * sizeof(double2), stream));
+            for (int k = 0; k < kp; ++k)
+                for (auto &sp : spans)
+                    PFB_HIP(hipMemsetAsync(d_grid.p + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv), 0,
+                                           size_t(sp.nrows) * size_t(info.nv) * sizeof(double2), stream));
             timer.end();
             timer.begin(0);
-            PFB_W_DISPATCH(launch_grid_w, p, sval);
+            if (kp_max > 1) {
+                PFB_W_DISPATCH(launch_grid_mp_w, p0, kp, sval);
+            } else {
+                PFB_W_DISPATCH(launch_grid_w, p0, sval);
+            }
             PFB_HIP(hipGetLastError());
             timer.end();
-            fft_rows_A(false);
-            timer.begin(4);
-            hipLaunchKernelGGL(k_a2b, tgrid(info.nu, prm.ny), dim3(TP, 8), 0, stream, geom, d_occ.p, d_grid.p, d_gridB.p);
-            PFB_HIP(hipGetLastError());
-            timer.end();
-            fft_rows_B(false);
-            timer.begin(4);
-            hipLaunchKernelGGL(k_crop_screen_T, dim3(uint32_t(ceil_div(prm.nx, 256)), uint32_t(prm.ny)), dim3(256), 0,
-                               stream, geom, d_gridB.p, prm.do_wgridding, wplanes[size_t(p)], p == 0 ? 1 : 0, d_accT.p);
-            PFB_HIP(hipGetLastError());
-            timer.end();
+            for (int k = 0; k < kp; ++k) {
+                const int p = p0 + k;
+                fft_rows_A(false, k);
+                timer.begin(4);
+                hipLaunchKernelGGL(k_a2b, tgrid(info.nu, prm.ny), dim3(TP, 8), 0, stream, geom, d_occ.p,
+                                   d_grid.p + size_t(k) * plane_stride, d_gridB.p);
+                PFB_HIP(hipGetLastError());
+                timer.end();
+                fft_rows_B(false);
+                timer.begin(4);
+                hipLaunchKernelGGL(k_crop_screen_T, dim3(uint32_t(ceil_div(prm.nx, 256)), uint32_t(prm.ny)), dim3(256),
+                                   0, stream, geom, d_gridB.p, prm.do_wgridding, wplanes[size_t(p)], p == 0 ? 1 : 0,
+                                   d_accT.p);
+                PFB_HIP(hipGetLastError());
+                timer.end();
+            }
         }
     }
 
@@ -753,20 +807,29 @@ struct pfbhip_gridder {
     {
         PFB_HIP(hipMemsetAsync(sacc, 0, size_t(std::max<int64_t>(info.nactive, 1)) * sizeof(double2), stream));
         if (info.nactive == 0 || info.nwork == 0) return;
-        for (int p = 0; p < info.nplanes; ++p) {
-            timer.begin(3);
-            hipLaunchKernelGGL(k_pad_screen_T, dim3(uint32_t(ceil_div(info.nu, 256)), uint32_t(prm.ny)), dim3(256), 0,
-                               stream, geom, d_accT.p, prm.do_wgridding, wplanes[size_t(p)], d_gridB.p);
-            PFB_HIP(hipGetLastError());
-            timer.end();
-            fft_rows_B(true);
-            timer.begin(3);
-            hipLaunchKernelGGL(k_b2a, tgrid(info.nu, info.nv), dim3(TP, 8), 0, stream, geom, d_occ.p, d_gridB.p, d_grid.p);
-            PFB_HIP(hipGetLastError());
-            timer.end();
-            fft_rows_A(true);
+        for (int p0 = 0; p0 < info.nplanes; p0 += kp_max) {
+            const int kp = int(std::min<int64_t>(kp_max, info.nplanes - p0));
+            for (int k = 0; k < kp; ++k) {
+                const int p = p0 + k;
+                timer.begin(3);
+                hipLaunchKernelGGL(k_pad_screen_T, dim3(uint32_t(ceil_div(info.nu, 256)), uint32_t(prm.ny)), dim3(256),
+                                   0, stream, geom, d_accT.p, prm.do_wgridding, wplanes[size_t(p)], d_gridB.p);
+                PFB_HIP(hipGetLastError());
+                timer.end();
+                fft_rows_B(true);
+                timer.begin(3);
+                hipLaunchKernelGGL(k_b2a, tgrid(info.nu, info.nv), dim3(TP, 8), 0, stream, geom, d_occ.p, d_gridB.p,
+                                   d_grid.p + size_t(k) * plane_stride);
+                PFB_HIP(hipGetLastError());
+                timer.end();
+                fft_rows_A(true, k);
+            }
             timer.begin(1);
-            PFB_W_DISPATCH(launch_degrid_w, p, sacc);
+            if (kp_max > 1) {
+                PFB_W_DISPATCH(launch_degrid_mp_w, p0, kp, sacc);
+            } else {
+                PFB_W_DISPATCH(launch_degrid_w, p0, sacc);
+            }
             PFB_HIP(hipGetLastError());
             timer.end();
         }
@@ -1106,7 +1169,9 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     PFB_HIP(hipGetLastError());
 
     // ---- scratch + FFT plans ----
-    g->d_grid.alloc(size_t(info.nu) * size_t(info.nv));
+    g->plane_stride = size_t(info.nu) * size_t(info.nv);
+    g->kp_max = int(std::min<int64_t>(KP_MAX, info.nplanes));
+    g->d_grid.alloc(g->plane_stride * size_t(g->kp_max));
     g->d_img.alloc(size_t(npix));
     g->d_sval.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
     g->d_sacc.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
@@ -1273,7 +1338,7 @@ int pfbhip_gridder_grid_plane(pfbhip_gridder *g, const double *vis_host, const d
         PFB_REQUIRE(plane >= 0 && plane < g->info.nplanes, "plane %lld out of range", (long long)plane);
         hipStream_t st = g->stream;
         g->upload_vis_wgt(vis_host, wgt_host);
-        PFB_HIP(hipMemsetAsync(g->d_grid.p, 0, g->d_grid.bytes(), st));
+        PFB_HIP(hipMemsetAsync(g->d_grid.p, 0, g->plane_stride * sizeof(double2), st));
         if (g->info.nactive && g->info.nwork) {
             hipLaunchKernelGGL(k_permute_in, blocks1d(g->info.nactive), dim3(256), 0, st, g->map, g->d_src.p,
                                g->info.nactive, g->d_vis.p, wgt_host ? g->d_wgt.p : nullptr, int(g->shifting),
@@ -1289,7 +1354,7 @@ int pfbhip_gridder_grid_plane(pfbhip_gridder *g, const double *vis_host, const d
             }
             PFB_HIP(hipGetLastError());
         }
-        PFB_HIP(hipMemcpyAsync(grid_host, g->d_grid.p, g->d_grid.bytes(), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipMemcpyAsync(grid_host, g->d_grid.p, g->plane_stride * sizeof(double2), hipMemcpyDeviceToHost, st));
         PFB_HIP(hipStreamSynchronize(st));
     });
 }

@@ -1,0 +1,277 @@
+// gridder_kernels_mp.hpp -- multi-plane variants of the scatter / gather kernels.
+//
+// A visibility's W x W footprint (u- and v-kernel values, LDS addresses) is the same on every
+// w-plane it touches; only a scalar plane weight differs.  These kernels keep the tiles of up to
+// KP = 4 consecutive planes in LDS at once (one 1024-thread workgroup per CU, ~150 KiB of the
+// 160 KiB), evaluate the footprint once per visibility and scatter / gather it on all KP
+// planes.  The per-visibility VALU work (record loads, two Horner chains, DPP rotations,
+// addressing) is shared by the planes; what remains per plane is the LDS traffic itself
+// (ds_add_f64 scatter, ds_read_b128 gather), which is the floor of this design.
+//
+// Plane weights: lane b (< kp) of every 16-lane row evaluates the weight of plane plane0 + b of
+// its row's visibility (Lagrange basis polynomial at the visibility's abscissa, or the W-wide ES
+// kernel in w); the KP values are then broadcast inside the row.
+#pragma once
+#include "gridder_kernels.hpp"
+
+namespace pfbhip {
+
+constexpr int KP_MAX = 4;
+constexpr int MP_THREADS = 1024;
+
+struct GroupArgs {
+    PlaneArgs a;             // a.plane = first plane of the group
+    int kp;                  // planes in this group (1..KP_MAX)
+    double coefk[KP_MAX];    // wmode 1: Lagrange denominators of the group's planes
+    size_t plane_stride;     // complex elements between consecutive planes of the uv-grid buffer
+};
+
+// weight of plane `plane` for abscissa/coordinate pw
+template <int W, int D>
+__device__ __forceinline__ double plane_weight_of(const PlaneArgs &a, int plane, double coef, double pw, const double *wtab)
+{
+    if (!a.do_w) return 1.0;
+    if (a.wmode == 0) {
+        const double shift = 1.0 - 0.5 * double(W);
+        const double fl = floor(pw + shift);
+        const int dp = plane - (int)fl;
+        if (dp < 0 || dp >= W) return 0.0;
+        const double z = 2.0 * ((pw + shift) - fl) - 1.0;
+        const double *c = wtab + dp * (D + 1);
+        double v = c[D];
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k) v = fma(v, z, c[k]);
+        return v;
+    }
+    double kw = coef;
+    for (int m = 0; m < a.nplanes; ++m)
+        if (m != plane) kw *= (pw - a.nodes[m]);
+    return kw;
+}
+
+// value held by lane `k` of this lane's 16-lane row
+__device__ __forceinline__ double row_bcast_f64(double v, int k)
+{
+    const int src = ((threadIdx.x & 63) & ~15) + k;
+    return __shfl(v, src);
+}
+
+template <int W>
+__global__ void __launch_bounds__(MP_THREADS) k_grid_mp(GroupArgs ga, const double2 *__restrict__ sval,
+                                                         double2 *__restrict__ grid)
+{
+    const PlaneArgs &a = ga.a;
+    constexpr int D = kernel_poly_degree_c(W);
+    constexpr int L = TILE + W - 1;
+    constexpr int LS = tile_stride(W);
+    constexpr int LL = tile_rows(W) * LS;
+    extern __shared__ double lds[];
+    double *wtab = lds + 2 * KP_MAX * LL;
+    const int kp = ga.kp;
+
+    uint32_t item = blockIdx.x;
+    if (item >= a.nwork) return;
+    const WorkItem wi = a.work[item];
+    for (int i = threadIdx.x; i < 2 * kp * LL; i += MP_THREADS) lds[i] = 0.0;
+    for (int i = threadIdx.x; i < W * (D + 1); i += MP_THREADS) wtab[i] = a.ktab[i];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = lane & 15, g = lane >> 4;
+    double c[D + 1];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) c[k] = b < W ? a.ktab[b * (D + 1) + k] : 0.0;
+    const double mycoef = b < KP_MAX ? ga.coefk[b] : 0.0;
+    __syncthreads();
+
+    const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
+    const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
+    const double shift = 1.0 - 0.5 * double(W);
+
+    const uint32_t stride = (MP_THREADS / 64) * 4;
+    uint32_t j = wi.begin + wave * 4 + g;
+    bool valid = j < wi.end;
+    double pu = valid ? a.pu[j] : 0.0, pv = valid ? a.pv[j] : 0.0, pw = (valid && a.do_w) ? a.pw[j] : 0.0;
+    double2 val = valid ? sval[j] : make_double2(0.0, 0.0);
+    for (uint32_t jb = wi.begin + wave * 4; jb < wi.end; jb += stride) {
+        const uint32_t jn = j + stride;
+        const bool nvalid = jn < wi.end;
+        const double npu = nvalid ? a.pu[jn] : 0.0, npv = nvalid ? a.pv[jn] : 0.0;
+        const double npw = (nvalid && a.do_w) ? a.pw[jn] : 0.0;
+        const double2 nval = nvalid ? sval[jn] : make_double2(0.0, 0.0);
+        {
+            double kwl = (b < kp && valid) ? plane_weight_of<W, D>(a, a.plane + b, mycoef, pw, wtab) : 0.0;
+            const double fu = floor(pu + shift), fv = floor(pv + shift);
+            const double zu = 2.0 * ((pu + shift) - fu) - 1.0, zv = 2.0 * ((pv + shift) - fv) - 1.0;
+            double ku = horner<D>(c, zu);
+            const double kv = horner<D>(c, zv);
+            const int lu = wrap_once((int)fu, a.nu) - bu, lv = wrap_once((int)fv, a.nv) - bv;
+            double vr[KP_MAX], vi[KP_MAX];
+            bool touch = false;  // uniform over the 16-lane row
+#pragma unroll
+            for (int k = 0; k < KP_MAX; ++k) {
+                const double kw = row_bcast_f64(kwl, k);
+                touch = touch || (kw != 0.0);
+                vr[k] = val.x * (kw * kv);
+                vi[k] = val.y * (kw * kv);
+            }
+            const int colbase = lu * LS + lv + b;
+            int arow = b;
+            if (touch) {  // rows whose visibility touches no plane of the group (or is past the end) sit out
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int off = colbase + arow * LS;
+                    if (W >= 14 || (arow < W && b < W)) {
+#pragma unroll
+                        for (int k = 0; k < KP_MAX; ++k)
+                            if (k < kp) {
+                                unsafeAtomicAdd(&lds[(2 * k) * LL + off], vr[k] * ku);
+                                unsafeAtomicAdd(&lds[(2 * k + 1) * LL + off], vi[k] * ku);
+                            }
+                    }
+                    ku = rot1_f64(ku);
+                    arow = rot1_i32(arow);
+                }
+            }
+        }
+        j = jn;
+        valid = nvalid;
+        pu = npu;
+        pv = npv;
+        pw = npw;
+        val = nval;
+    }
+    __syncthreads();
+    for (int k = 0; k < kp; ++k) {
+        double *gp = reinterpret_cast<double *>(grid + size_t(k) * ga.plane_stride);
+        const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
+        for (int i = threadIdx.x; i < L * L; i += MP_THREADS) {
+            const int la = i / L, lb = i - la * L;
+            const double re = lre[la * LS + lb], im = lim[la * LS + lb];
+            if (re != 0.0 || im != 0.0) {
+                int gu = bu + la, gv = bv + lb;
+                gu = gu >= a.nu ? gu % a.nu : gu;
+                gv = gv >= a.nv ? gv % a.nv : gv;
+                const size_t o = (size_t(gu) * size_t(a.nv) + size_t(gv)) * 2;
+                unsafeAtomicAdd(&gp[o], re);
+                unsafeAtomicAdd(&gp[o + 1], im);
+            }
+        }
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const double2 *__restrict__ grid,
+                                                           double2 *__restrict__ sacc)
+{
+    const PlaneArgs &a = ga.a;
+    constexpr int D = kernel_poly_degree_c(W);
+    constexpr int L = TILE + W - 1;
+    constexpr int LS = tile_stride(W);
+    constexpr int LL = tile_rows(W) * LS;
+    extern __shared__ double lds[];
+    double2 *tiles = reinterpret_cast<double2 *>(lds);  // KP_MAX tiles of LL complex
+    double *wtab = lds + 2 * KP_MAX * LL;
+    const int kp = ga.kp;
+
+    uint32_t item = blockIdx.x;
+    if (item >= a.nwork) return;
+    const WorkItem wi = a.work[item];
+    const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
+    const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
+    for (int k = 0; k < kp; ++k) {
+        const double2 *gk = grid + size_t(k) * ga.plane_stride;
+        for (int i = threadIdx.x; i < LL; i += MP_THREADS) {
+            const int la = i / LS, lb = i - la * LS;
+            double2 v = make_double2(0.0, 0.0);
+            if (la < L && lb < L) {
+                int gu = bu + la, gv = bv + lb;
+                gu = gu >= a.nu ? gu % a.nu : gu;
+                gv = gv >= a.nv ? gv % a.nv : gv;
+                v = gk[size_t(gu) * size_t(a.nv) + size_t(gv)];
+            }
+            tiles[k * LL + i] = v;
+        }
+    }
+    for (int i = threadIdx.x; i < W * (D + 1); i += MP_THREADS) wtab[i] = a.ktab[i];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = lane & 15, g = lane >> 4;
+    double c[D + 1];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) c[k] = b < W ? a.ktab[b * (D + 1) + k] : 0.0;
+    const double mycoef = b < KP_MAX ? ga.coefk[b] : 0.0;
+    __syncthreads();
+
+    const double shift = 1.0 - 0.5 * double(W);
+    const uint32_t stride = (MP_THREADS / 64) * 4;
+    uint32_t j = wi.begin + wave * 4 + g;
+    bool valid = j < wi.end;
+    double pu = valid ? a.pu[j] : 0.0, pv = valid ? a.pv[j] : 0.0, pw = (valid && a.do_w) ? a.pw[j] : 0.0;
+    for (uint32_t jb = wi.begin + wave * 4; jb < wi.end; jb += stride) {
+        const uint32_t jn = j + stride;
+        const bool nvalid = jn < wi.end;
+        const double npu = nvalid ? a.pu[jn] : 0.0, npv = nvalid ? a.pv[jn] : 0.0;
+        const double npw = (nvalid && a.do_w) ? a.pw[jn] : 0.0;
+        {
+            double kwl = (b < kp && valid) ? plane_weight_of<W, D>(a, a.plane + b, mycoef, pw, wtab) : 0.0;
+            const double fu = floor(pu + shift), fv = floor(pv + shift);
+            const double zu = 2.0 * ((pu + shift) - fu) - 1.0, zv = 2.0 * ((pv + shift) - fv) - 1.0;
+            double ku = horner<D>(c, zu);
+            const double kv = horner<D>(c, zv);
+            const int lu = wrap_once((int)fu, a.nu) - bu, lv = wrap_once((int)fv, a.nv) - bv;
+            double kw[KP_MAX];
+#pragma unroll
+            for (int k = 0; k < KP_MAX; ++k) kw[k] = row_bcast_f64(kwl, k);
+            const bool touch = (kw[0] != 0.0) || (kw[1] != 0.0) || (kw[2] != 0.0) || (kw[3] != 0.0);
+            const int colbase = lu * LS + lv + b;
+            int arow = b;
+            double sr[KP_MAX] = {0.0, 0.0, 0.0, 0.0}, si[KP_MAX] = {0.0, 0.0, 0.0, 0.0};
+            if (touch) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int off = colbase + arow * LS;
+                    if (W >= 14 || (arow < W && b < W)) {
+#pragma unroll
+                        for (int k = 0; k < KP_MAX; ++k)
+                            if (k < kp) {
+                                const double2 gval = tiles[k * LL + off];
+                                sr[k] = fma(gval.x, ku, sr[k]);
+                                si[k] = fma(gval.y, ku, si[k]);
+                            }
+                    }
+                    ku = rot1_f64(ku);
+                    arow = rot1_i32(arow);
+                }
+            }
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int k = 0; k < KP_MAX; ++k) {
+                tr = fma(sr[k], kw[k], tr);
+                ti = fma(si[k], kw[k], ti);
+            }
+            tr *= kv;
+            ti *= kv;
+            tr += rotn_f64<8>(tr);
+            ti += rotn_f64<8>(ti);
+            tr += rotn_f64<4>(tr);
+            ti += rotn_f64<4>(ti);
+            tr += rotn_f64<2>(tr);
+            ti += rotn_f64<2>(ti);
+            tr += rotn_f64<1>(tr);
+            ti += rotn_f64<1>(ti);
+            if (b == 0 && touch) {
+                double2 acc = sacc[j];
+                acc.x += tr;
+                acc.y += ti;
+                sacc[j] = acc;
+            }
+        }
+        j = jn;
+        valid = nvalid;
+        pu = npu;
+        pv = npv;
+        pw = npw;
+    }
+}
+
+}  // namespace pfbhip
