@@ -41,13 +41,15 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
     P = info["nplanes"]
     b_vis = nactive * (2 * Sc + Sr + 2) + 2 * nrow * 24
     b_grid = P * (12 * G + 3 * I)
+    # scatter / gather launches cover up to 4 planes at once (multi-plane kernels)
+    ppl = P / -(-P // 4)
     per_launch = {
-        # one launch = one w-plane (fft: one axis of one w-plane)
-        "fft": 2 * G,                      # 1 read + 1 write of the plane per axis
-        "grid": G + nactive * (Sc + 24),   # plane written once + sorted vis value and (pu,pv,pw) record read
-        "degrid": G + nactive * (Sc + 24),  # plane read once + record read, vis accumulator updated
-        "pad_screen": G + I,               # image read, plane written
-        "crop_screen": G + 2 * I,          # plane read, image read-modify-write
+        # fft: one launch = one axis of one w-plane; pad/crop: one w-plane
+        "fft": 2 * G,                              # 1 read + 1 write of the plane per axis
+        "grid": ppl * (G + nactive * (Sc + 24)),   # per plane: plane written once + sorted vis value and (pu,pv,pw) read
+        "degrid": ppl * (G + nactive * (Sc + 24)),  # per plane: plane read once + record read, vis accumulator updated
+        "pad_screen": G + I,                       # image read, plane written
+        "crop_screen": G + 2 * I,                  # plane read, image read-modify-write
     }
     return b_vis + b_grid, per_launch
 
@@ -181,6 +183,7 @@ def main():
             except Exception:
                 traffic = None
         stage_ms = {s: round(v[0] / args.steps, 3) for s, v in stages.items()}
+        stage_launches = {s: v[1] / args.steps for s, v in stages.items()}
         out = {
             "metric": "Mvis/s gridded+degridded in exact Hessian applies (8192^2 grid, 1e7 vis/band)",
             "value": total_active * 2 / (elapsed / args.steps) / 1e6,
@@ -209,6 +212,7 @@ def main():
                 "apply_alg_bytes": b_apply,
                 "apply_frac": b_apply / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "stage_ms_per_step": stage_ms,
+                "stage_launches_per_step": stage_launches,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -76,7 +76,9 @@ int pfbhip_comm_reduce_sum(pfbhip_comm *c, const double *send_dev, double *recv_
         PFB_REQUIRE(c && send_dev && count >= 0, "NULL argument");
         PFB_REQUIRE(root >= 0 && root < c->nranks, "bad root %d", root);
         PFB_REQUIRE(recv_dev || c->rank != root, "root needs a receive buffer");
-        PFB_NCCL(ncclReduce(send_dev, recv_dev, size_t(count), ncclDouble, ncclSum, root, c->comm, c->stream));
+        // recvbuff is only significant on the root; other ranks may pass NULL (replaced by sendbuff)
+        void *rb = recv_dev ? static_cast<void *>(recv_dev) : const_cast<double *>(send_dev);
+        PFB_NCCL(ncclReduce(send_dev, rb, size_t(count), ncclDouble, ncclSum, root, c->comm, c->stream));
         PFB_HIP(hipStreamSynchronize(c->stream));
     });
 }

@@ -91,7 +91,9 @@ class BandComm:
         """RCCL sum-to-root of device buffers (the product's band reduce)."""
         assert self.transport == "rccl"
         n = int(np.prod(send.shape, dtype=np.int64))
-        check(lib().pfbhip_comm_reduce_sum(self._h, send.ptr, None if recv is None else recv.ptr, i64(n), cint(root)))
+        # non-root ranks pass their send buffer as the (unused) receive buffer, the usual NCCL idiom
+        rptr = send.ptr if recv is None else recv.ptr
+        check(lib().pfbhip_comm_reduce_sum(self._h, send.ptr, rptr, i64(n), cint(root)))
 
     def allreduce_sum_dev(self, send, recv):
         assert self.transport == "rccl"
