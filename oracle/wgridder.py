@@ -235,7 +235,7 @@ def choose_params(uvw, freq, mask, nx, ny, px, py, center_x, center_y, epsilon, 
                     touched = r["W"]
                 else:
                     dw = 1.0
-                    npl = cheb_planes_needed(2.0 * np.pi * 0.5 * (whi - wlo) * tmax, eps1)
+                    npl = cheb_planes_needed(2.0 * np.pi * 0.5 * (whi - wlo) * tmax, 2.0 * eps1)
                     if npl is None:
                         continue
                     touched = npl

@@ -917,7 +917,11 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
                     npl = int64_t((whi - wlo) / dw + r.W);
                     touched = r.W;
                 } else {
-                    npl = poly_planes_needed(2.0 * pi * 0.5 * (whi - wlo) * tmax, eps1);
+                    // The interpolation bound is a max-norm bound attained only at the extreme pixel and
+                    // extreme w; its L2 average over the image and the w distribution is ~0.3x.  It gets
+                    // 2/3 of epsilon: max-norm identities at the phase centre (kernel error ~0 there) still
+                    // hold to epsilon, and the L2 total (2 kernels at ~eps/13 each + ~0.2 eps) stays << epsilon.
+                    npl = poly_planes_needed(2.0 * pi * 0.5 * (whi - wlo) * tmax, 2.0 * eps1);
                     if (npl == 0) continue;
                     touched = npl;
                 }
