@@ -41,15 +41,18 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
     P = info["nplanes"]
     b_vis = nactive * (2 * Sc + Sr + 2) + 2 * nrow * 24
     b_grid = P * (12 * G + 3 * I)
-    # scatter / gather launches cover up to 4 planes at once (multi-plane kernels)
-    ppl = P / -(-P // 4)
+    # Per-launch compulsory bytes of the PRUNED pipeline actually run: only the
+    # occupied rows of the uv-plane A (nu,nv) are cleared / scattered / transformed, the second axis runs
+    # on the cropped, transposed plane B (ny,nu).  A launch = what the stage timers count.
+    occ = info["occ_rows"] / info["nu"]
+    B = ny * info["nu"] * Sc
+    ppl = P / -(-P // 4)  # planes per scatter / gather launch (multi-plane kernels, up to 4)
     per_launch = {
-        # fft: one launch = one axis of one w-plane; pad/crop: one w-plane
-        "fft": 2 * G,                              # 1 read + 1 write of the plane per axis
-        "grid": ppl * (G + nactive * (Sc + 24)),   # per plane: plane written once + sorted vis value and (pu,pv,pw) read
-        "degrid": ppl * (G + nactive * (Sc + 24)),  # per plane: plane read once + record read, vis accumulator updated
-        "pad_screen": G + I,                       # image read, plane written
-        "crop_screen": G + 2 * I,                  # plane read, image read-modify-write
+        "fft": (occ * G + B),                         # one row-FFT pass: 1 read + 1 write (average of the A and B passes)
+        "grid": ppl * (occ * G + nactive * (Sc + 24)),   # per plane: occupied plane rows written once + records read
+        "degrid": ppl * (occ * G + nactive * (Sc + 24)),  # per plane: occupied plane rows read once + records read
+        "pad_screen": (I + B + occ * B + occ * G) / 2,   # pad+screen (image -> B) and transpose+pad (B -> occupied A)
+        "crop_screen": (occ * (ny / info["nv"]) * G + B + (nx / info["nu"]) * B + 2 * I) / 2,  # A -> B, B -> image RMW
     }
     return b_vis + b_grid, per_launch
 
@@ -108,6 +111,7 @@ def main():
     ap.add_argument("--epsilon", type=float, default=1e-7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-planes", type=int, default=2)
+    ap.add_argument("--force", default=None, help="developer knob: 'sigma,W' pins the kernel row")
     args = ap.parse_args()
 
     from pfb_imaging_amd import _lib
@@ -137,7 +141,8 @@ def main():
     t0 = time.time()
     g = Gridder(case["uvw"], case["freq"], case["mask"], npix_x=nx, npix_y=ny, pixsize_x=case["cell"],
                 pixsize_y=case["cell"], center_x=0.0, center_y=0.0, epsilon=args.epsilon, flip_u=False, flip_v=True,
-                flip_w=False, do_wgridding=True, divide_by_n=False, sigma_min=1.1, sigma_max=3.0)
+                flip_w=False, do_wgridding=True, divide_by_n=False, sigma_min=1.1, sigma_max=3.0,
+                force=None if args.force is None else (float(args.force.split(",")[0]), int(args.force.split(",")[1])))
     g.set_weights(case["wgt"])
     t_plan = time.time() - t0
     info = g.info
@@ -213,6 +218,8 @@ def main():
                 "apply_frac": b_apply / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "stage_ms_per_step": stage_ms,
                 "stage_launches_per_step": stage_launches,
+                "stage_achieved_gbs": {s: round(per_launch[s] / (stages[s][0] / max(stages[s][1], 1) * 1e-3) / 1e9, 1)
+                                       for s in per_launch if stages[s][1]},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

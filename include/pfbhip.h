@@ -99,7 +99,8 @@ typedef struct pfbhip_gridder_info {
      * wcenter + whalf] is interpolated by a degree-(nplanes-1) polynomial through Chebyshev
      * nodes (each visibility touches all planes with Lagrange weights; no w-correction in the
      * image).  The cheaper admissible scheme is chosen per plan. */
-    int32_t wmode, reserved;
+    int32_t wmode;
+    int32_t occ_rows;      /* rows of the uv-plane that hold visibilities (only these are cleared / transformed) */
     double wcenter, whalf;
     size_t device_bytes;   /* device memory held by the handle                */
 } pfbhip_gridder_info;

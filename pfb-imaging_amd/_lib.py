@@ -37,7 +37,7 @@ class GridderInfo(ct.Structure):
         ("nu", i64), ("nv", i64), ("nplanes", i64), ("nactive", i64), ("ntiles", i64), ("nwork", i64),
         ("W", i32), ("tile", i32), ("beta", f64), ("sigma", f64), ("wmin", f64), ("dw", f64),
         ("nshift", f64), ("lshift", f64), ("mshift", f64), ("kernel_eps", f64),
-        ("wmode", i32), ("reserved", i32), ("wcenter", f64), ("whalf", f64), ("device_bytes", ct.c_size_t),
+        ("wmode", i32), ("occ_rows", i32), ("wcenter", f64), ("whalf", f64), ("device_bytes", ct.c_size_t),
     ]
 
     def asdict(self):

@@ -954,7 +954,7 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
     info.nplanes = bnpl;
     info.dw = bdw;
     info.wmode = bmode;
-    info.reserved = 0;
+    info.occ_rows = 0;
     info.wcenter = 0.5 * (wlo + whi);
     info.whalf = 0.5 * (whi - wlo);
     info.wmin = (prm.do_wgridding && bmode == 0) ? 0.5 * (wlo + whi) - 0.5 * double(bnpl - 1) * bdw : 0.0;
@@ -1236,6 +1236,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     }
     g->fftB_fwd = make_rows(info.nu, prm.ny, true);
     g->fftB_bwd = make_rows(info.nu, prm.ny, false);
+    info.occ_rows = int32_t(g->occ_rows);
     PFB_ROCFFT(rocfft_execution_info_create(&g->fft_info));
     if (wmax) {
         g->d_fftwork.alloc(wmax);
