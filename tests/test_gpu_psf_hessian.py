@@ -226,3 +226,47 @@ def test_band_pool_residual_and_mfs():
     np.testing.assert_allclose(mfs, res.sum(axis=0) / 3.0, rtol=1e-12, atol=1e-12)
     with pytest.raises(NotImplementedError):
         pool.init_psi(nx, ny, ["self"], 2)
+
+
+@pytest.mark.parametrize("center_offset", [(0.0, 0.0), (0.1, -0.17), (0.2, 0.5), (-0.1, 0.2), (-0.15, -0.2)])
+def test_hessian_equals_psf_convolution(center_offset):
+    """/root/reference/tests/test_hessian_approx.py:234-307 (test_hessian), same steps, same tolerance:
+    hessian_slice(delta) with do_wgridding=False == psf_convolve_slice(delta) with the PSF gridded from
+    the phase-ramp visibilities; all through the GPU path."""
+    from pfb_imaging_amd.fft import good_size, r2c
+    from pfb_imaging_amd.operators.gridder import wgridder_conventions
+    from pfb_imaging_amd.operators.hessian import hessian_slice
+    from pfb_imaging_amd.operators.psf import psf_convolve_slice
+    from pfb_imaging_amd.utils import synth
+    from pfb_imaging_amd.wgridder import vis2dirty
+
+    c = synth.make_case(3000, 2, 64, seed=9)
+    uvw, freq = c["uvw"], c["freq"]
+    nrow, nchan = c["vis"].shape
+    nx = ny = 64
+    nx_psf = ny_psf = good_size(int(1.5 * nx))
+    cell_rad = c["cell"]
+    x0, y0 = center_offset
+    flip_u, flip_v, flip_w, x0, y0 = wgridder_conventions(x0, y0)
+    epsilon = 1e-10
+    signu = -1.0 if flip_u else 1.0
+    signv = -1.0 if flip_v else 1.0
+    signx = -1.0 if flip_u else 1.0
+    signy = -1.0 if flip_v else 1.0
+    freqfactor = -2j * np.pi * freq[None, :] / 299792458.0
+    psf_vis = np.exp(freqfactor * (signu * uvw[:, 0:1] * x0 * signx + signv * uvw[:, 1:2] * y0 * signy))
+    x = np.zeros((nx, ny), dtype="f8")
+    x[nx // 2, ny // 2] = 1.0
+    psf = vis2dirty(uvw=uvw, freq=freq, vis=psf_vis, wgt=None, npix_x=nx_psf, npix_y=ny_psf, pixsize_x=cell_rad,
+                    pixsize_y=cell_rad, center_x=x0, center_y=y0, flip_u=flip_u, flip_v=flip_v, flip_w=flip_w,
+                    epsilon=epsilon, do_wgridding=False, divide_by_n=False, nthreads=2, verbosity=0)
+    psfhat = r2c(np.fft.ifftshift(psf, axes=(0, 1)), axes=(0, 1), nthreads=2, forward=True, inorm=0)
+    res1 = hessian_slice(x, uvw=uvw, weight=np.ones((nrow, nchan), dtype="f8"),
+                         vis_mask=np.ones((nrow, nchan), dtype=np.uint8), freq=freq, cell=cell_rad, x0=x0, y0=y0,
+                         flip_u=flip_u, flip_v=flip_v, flip_w=flip_w, do_wgridding=False, epsilon=epsilon,
+                         double_accum=True, nthreads=2)
+    res2 = psf_convolve_slice(np.zeros((nx_psf, ny_psf)), np.zeros_like(psfhat), np.zeros_like(x), psfhat, ny_psf, x,
+                              nthreads=2)
+    scale = np.abs(res2).max()
+    diff = (res2 - res1) / scale
+    assert np.allclose(1 + diff, 1)
