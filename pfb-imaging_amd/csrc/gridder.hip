@@ -254,85 +254,6 @@ __global__ void k_corr_image(ImgGeom g, const double *cfu, const double *cfv, co
     corr[p] = c;
 }
 
-// out = a * b [* c]
-__global__ void k_mul_images(int64_t n, const double *a, const double *b, const double *c, double *out)
-{
-    int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-    if (p >= n) return;
-    double v = a[p] * b[p];
-    if (c) v *= c[p];
-    out[p] = v;
-}
-
-// out = acc * corr [* beam] * scale + eta * x
-__global__ void k_finalize(int64_t n, const double *acc, const double *corr, const double *beam, double scale,
-                           double eta, const double *x, double *out)
-{
-    int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-    if (p >= n) return;
-    double v = acc[p] * corr[p];
-    if (beam) v *= beam[p];
-    v *= scale;
-    if (x) v += eta * x[p];
-    out[p] = v;
-}
-
-// degrid side: grid[wrap(ix - nx/2), wrap(iy - ny/2)] = dc[ix,iy] * exp(+2 pi i w_p t), 0 elsewhere.
-// One thread per grid cell: the whole plane is written exactly once (no memset needed).
-__global__ void k_pad_screen(ImgGeom g, const double *dc, int do_w, double wplane, double2 *grid)
-{
-    int iv = blockIdx.x * blockDim.x + threadIdx.x;
-    int iu = blockIdx.y;
-    if (iv >= g.nv) return;
-    const int hx = g.nx / 2, hy = g.ny / 2;
-    int ix = -1, iy = -1;
-    if (iu < g.nx - hx) ix = iu + hx;
-    else if (iu >= g.nu - hx) ix = iu - (g.nu - hx);
-    if (iv < g.ny - hy) iy = iv + hy;
-    else if (iv >= g.nv - hy) iy = iv - (g.nv - hy);
-    double2 out = make_double2(0.0, 0.0);
-    if (ix >= 0 && iy >= 0) {
-        double val = dc[size_t(ix) * g.ny + iy];
-        if (do_w) {
-            double ph = wplane * pixel_t(g, ix, iy);
-            ph -= rint(ph);
-            double s, c;
-            sincospi(2.0 * ph, &s, &c);
-            out.x = val * c;
-            out.y = val * s;
-        } else {
-            out.x = val;
-        }
-    }
-    grid[size_t(iu) * g.nv + iv] = out;
-}
-
-// grid side: acc[ix,iy] (+)= Re( grid[wrap] * exp(-2 pi i w_p t) )
-__global__ void k_crop_screen(ImgGeom g, const double2 *grid, int do_w, double wplane, int first, double *acc)
-{
-    int iy = blockIdx.x * blockDim.x + threadIdx.x;
-    int ix = blockIdx.y;
-    if (iy >= g.ny) return;
-    const int hx = g.nx / 2, hy = g.ny / 2;
-    int iu = ix - hx;
-    if (iu < 0) iu += g.nu;
-    int iv = iy - hy;
-    if (iv < 0) iv += g.nv;
-    double2 v = grid[size_t(iu) * g.nv + iv];
-    double r;
-    if (do_w) {
-        double ph = wplane * pixel_t(g, ix, iy);
-        ph -= rint(ph);
-        double s, c;
-        sincospi(2.0 * ph, &s, &c);
-        r = v.x * c + v.y * s;
-    } else {
-        r = v.x;
-    }
-    size_t o = size_t(ix) * g.ny + iy;
-    acc[o] = first ? r : acc[o] + r;
-}
-
 // ---------------------------------------------------------------------------------------
 // pruned two-pass plane transform
 // ---------------------------------------------------------------------------------------
@@ -576,7 +497,7 @@ struct pfbhip_gridder {
     DevBuf<WorkItem> d_work;
     // scratch
     DevBuf<double2> d_grid, d_sval, d_sacc, d_vis;
-    DevBuf<double> d_wgt, d_swgt, d_acc, d_img, d_img2, d_beam;
+    DevBuf<double> d_wgt, d_swgt, d_img, d_img2, d_beam;
     DevBuf<char> d_fftwork;
     DevBuf<double2> d_gridB;  // (ny, nu) transposed / cropped plane
     DevBuf<double> d_accT;    // (ny, nx) transposed image accumulator / transposed degrid input
@@ -613,7 +534,7 @@ struct pfbhip_gridder {
         return d_uvw.bytes() + d_fc.bytes() + d_pu.bytes() + d_pv.bytes() + d_pw.bytes() + d_corr.bytes() +
                d_cfu.bytes() + d_cfv.bytes() + d_cheb.bytes() + d_ktab.bytes() + d_mask.bytes() + d_src.bytes() + d_work.bytes() +
                d_grid.bytes() + d_sval.bytes() + d_sacc.bytes() + d_vis.bytes() + d_wgt.bytes() + d_swgt.bytes() +
-               d_acc.bytes() + d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes() + d_gridB.bytes() +
+               d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes() + d_gridB.bytes() +
                d_accT.bytes() + d_occ.bytes();
     }
 

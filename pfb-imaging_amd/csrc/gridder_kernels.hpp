@@ -95,12 +95,6 @@ __device__ __forceinline__ double horner(const double (&c)[D + 1], double z)
     return v;
 }
 
-// One visibility's record as seen by its 16-lane row.
-struct RowVis {
-    double pu, pv, pw;
-    bool valid;
-};
-
 // w-plane weight of a visibility for plane a.plane (0 = does not touch the plane)
 template <int W, int D>
 __device__ __forceinline__ double plane_weight(const PlaneArgs &a, double pw, const double *wtab /* LDS (W, D+1) */)
