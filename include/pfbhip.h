@@ -225,6 +225,13 @@ int pfbhip_counts_divide(const double *uvw_host, const double *freq_host, const 
                          const double *counts_host, int64_t ncorr, int64_t nrow, int64_t nchan, int64_t nx,
                          int64_t ny, double cell_x, double cell_y, double usign, double vsign, double *wgt_host);
 
+/* box_sum_counts (utils/weighting.py:229-254): (2 s + 1)^2 box sum with zero padding, per correlation plane. */
+int pfbhip_box_sum_counts(const double *counts_host, int64_t ncorr, int64_t nx, int64_t ny, int64_t npix_super,
+                          double *out_host);
+/* filter_extreme_counts (utils/weighting.py:212-226): positive counts below median(positive)/level are
+ * raised to that value, in place; the median is returned through median_out (may be NULL). */
+int pfbhip_filter_extreme_counts(double *counts_host, int64_t n, double level, double *median_out);
+
 /* ---- band reduce over xGMI (RCCL) ------------------------------------ */
 /*
  * Replaces the driver-side band sums of the reference

@@ -51,3 +51,30 @@ def counts_to_weights(counts, uvw, freq, weight, mask, nx, ny, cell_x, cell_y, r
     cell = uvcell_index(uvw, freq, mask, nx, ny, cell_x, cell_y, usign, vsign)
     lib().pfbo_counts_divide(i64(ncorr), i64(nrow), i64(nchan), ptr(cell), ptr(counts), i64(nx * ny), ptr(weight))
     return weight
+
+
+def filter_extreme_counts(counts, level=10.0):
+    """weighting.py:212-226 restated."""
+    if not level:
+        return counts
+    pos = counts > 0
+    if not pos.any():
+        return counts
+    lowval = np.median(counts[pos]) / level
+    counts[pos] = np.maximum(counts[pos], lowval)
+    return counts
+
+
+def box_sum_counts(counts, npix_super):
+    """weighting.py:229-254 restated (explicit zero-padded window sums instead of uniform_filter * size^2)."""
+    if npix_super is None or npix_super <= 0:
+        return counts
+    s = int(npix_super)
+    ncorr, nx, ny = counts.shape
+    pad = np.zeros((ncorr, nx + 2 * s, ny + 2 * s), dtype=counts.dtype)
+    pad[:, s:s + nx, s:s + ny] = counts
+    out = np.zeros_like(counts)
+    for dx in range(2 * s + 1):
+        for dy in range(2 * s + 1):
+            out += pad[:, dx:dx + nx, dy:dy + ny]
+    return out

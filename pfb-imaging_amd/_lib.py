@@ -63,7 +63,8 @@ SYMBOLS = (
     "pfbhip_r2c_2d", "pfbhip_c2r_2d",
     "pfbhip_psfconv_create", "pfbhip_psfconv_destroy", "pfbhip_psfconv_set_psfhat", "pfbhip_psfconv_set_beam",
     "pfbhip_psfconv_apply", "pfbhip_psfconv_apply_dev", "pfbhip_psfconv_cg",
-    "pfbhip_uvcell_index", "pfbhip_compute_counts", "pfbhip_counts_divide",
+    "pfbhip_uvcell_index", "pfbhip_compute_counts", "pfbhip_counts_divide", "pfbhip_box_sum_counts",
+    "pfbhip_filter_extreme_counts",
     "pfbhip_comm_unique_id", "pfbhip_comm_create", "pfbhip_comm_destroy", "pfbhip_comm_reduce_sum",
     "pfbhip_comm_allreduce_sum", "pfbhip_comm_barrier",
 )

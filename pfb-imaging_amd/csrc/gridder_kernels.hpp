@@ -29,7 +29,7 @@
 
 namespace pfbhip {
 
-constexpr int CHUNK = 2048;        // sorted visibilities per work item
+constexpr int CHUNK = 4096;        // sorted visibilities per work item
 constexpr int GRID_THREADS = 256;  // 4 wavefronts per workgroup
 
 struct WorkItem {

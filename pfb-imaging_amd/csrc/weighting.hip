@@ -6,6 +6,8 @@
 // pfbo_uvcell_index): identical un-fused IEEE double sequence, compiled -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <hipcub/hipcub.hpp>
+
 #include "common.hpp"
 
 namespace pfbhip {
@@ -102,6 +104,41 @@ struct CellSetup {
     dim3 grid() const { return dim3(uint32_t(std::max<int64_t>(ceil_div(a.nvis, 256), 1))); }
 };
 
+// box sum along one axis with zero padding: out[r][c] = sum_{|d| <= s} in[r][c + d]   (axis 1)
+//                                              or  sum_{|d| <= s} in[r + d][c]   (axis 0)
+__global__ void k_box_sum_axis(const double *in, int64_t nplanes, int nx, int ny, int s, int axis, double *out)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t per = int64_t(nx) * ny;
+    if (i >= nplanes * per) return;
+    const int64_t pl = i / per, o = i - pl * per;
+    const int r = int(o / ny), c = int(o - int64_t(r) * ny);
+    const double *p = in + pl * per;
+    double acc = 0.0;
+    if (axis == 1) {
+        for (int d = -s; d <= s; ++d) {
+            int cc = c + d;
+            if (cc >= 0 && cc < ny) acc += p[int64_t(r) * ny + cc];
+        }
+    } else {
+        for (int d = -s; d <= s; ++d) {
+            int rr = r + d;
+            if (rr >= 0 && rr < nx) acc += p[int64_t(rr) * ny + c];
+        }
+    }
+    out[i] = acc;
+}
+
+struct IsPositive {
+    __host__ __device__ bool operator()(const double &v) const { return v > 0.0; }
+};
+
+__global__ void k_floor_positive(double *a, int64_t n, double lowval)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i < n && a[i] > 0.0 && a[i] < lowval) a[i] = lowval;
+}
+
 }  // namespace pfbhip
 
 using namespace pfbhip;
@@ -157,6 +194,55 @@ int pfbhip_counts_divide(const double *uvw_host, const double *freq_host, const 
         hipLaunchKernelGGL(k_counts_divide, s.grid(), dim3(256), 0, 0, s.a, counts.p, int(ncorr), wgt.p);
         PFB_HIP(hipGetLastError());
         PFB_HIP(hipMemcpy(wgt_host, wgt.p, wgt.bytes(), hipMemcpyDeviceToHost));
+    });
+}
+
+int pfbhip_box_sum_counts(const double *counts_host, int64_t ncorr, int64_t nx, int64_t ny, int64_t npix_super,
+                          double *out_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(counts_host && out_host && ncorr >= 1 && nx >= 1 && ny >= 1 && npix_super >= 0, "bad arguments");
+        const size_t n = size_t(ncorr) * size_t(nx) * size_t(ny);
+        DevBuf<double> a(n), b(n);
+        PFB_HIP(hipMemcpy(a.p, counts_host, n * sizeof(double), hipMemcpyHostToDevice));
+        dim3 grid(uint32_t(ceil_div(int64_t(n), 256)));
+        hipLaunchKernelGGL(k_box_sum_axis, grid, dim3(256), 0, 0, a.p, ncorr, int(nx), int(ny), int(npix_super), 1, b.p);
+        hipLaunchKernelGGL(k_box_sum_axis, grid, dim3(256), 0, 0, b.p, ncorr, int(nx), int(ny), int(npix_super), 0, a.p);
+        PFB_HIP(hipGetLastError());
+        PFB_HIP(hipMemcpy(out_host, a.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+int pfbhip_filter_extreme_counts(double *counts_host, int64_t n, double level, double *median_out)
+{
+    return guarded([&] {
+        PFB_REQUIRE(counts_host && n >= 0 && level > 0.0, "bad arguments");
+        PFB_REQUIRE(n < (int64_t(1) << 31), "counts grid too large");
+        if (median_out) *median_out = 0.0;
+        if (n == 0) return;
+        DevBuf<double> a{size_t(n)}, pos{size_t(n)}, sorted{size_t(n)};
+        DevBuf<int> d_num(1);
+        PFB_HIP(hipMemcpy(a.p, counts_host, size_t(n) * sizeof(double), hipMemcpyHostToDevice));
+        size_t tb = 0;
+        PFB_HIP(hipcub::DeviceSelect::If(nullptr, tb, a.p, pos.p, d_num.p, int(n), IsPositive()));
+        DevBuf<char> tmp(tb);
+        PFB_HIP(hipcub::DeviceSelect::If(tmp.p, tb, a.p, pos.p, d_num.p, int(n), IsPositive()));
+        int npos = 0;
+        PFB_HIP(hipMemcpy(&npos, d_num.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (npos == 0) return;
+        size_t sb = 0;
+        PFB_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, sb, pos.p, sorted.p, npos));
+        DevBuf<char> stmp(sb);
+        PFB_HIP(hipcub::DeviceRadixSort::SortKeys(stmp.p, sb, pos.p, sorted.p, npos));
+        double mid[2] = {0.0, 0.0};
+        const int lo = (npos - 1) / 2, hi = npos / 2;  // numpy.median: mean of the two middle values
+        PFB_HIP(hipMemcpy(&mid[0], sorted.p + lo, sizeof(double), hipMemcpyDeviceToHost));
+        PFB_HIP(hipMemcpy(&mid[1], sorted.p + hi, sizeof(double), hipMemcpyDeviceToHost));
+        const double med = 0.5 * (mid[0] + mid[1]);
+        if (median_out) *median_out = med;
+        hipLaunchKernelGGL(k_floor_positive, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, 0, a.p, n, med / level);
+        PFB_HIP(hipGetLastError());
+        PFB_HIP(hipMemcpy(counts_host, a.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost));
     });
 }
 

@@ -58,3 +58,30 @@ def counts_to_weights(counts, uvw, freq, weight, mask, nx, ny, cell_size_x, cell
     if w is not weight:
         weight[...] = w
     return weight
+
+
+def filter_extreme_counts(counts, level=10.0):
+    """weighting.py:212-226: positive counts below ``median(positive)/level`` are raised to it (in place)."""
+    if not level:
+        return counts
+    _lib.require_gpu()
+    c = counts if (counts.flags.c_contiguous and counts.dtype == np.float64) else np.array(counts, dtype=np.float64)
+    check(lib().pfbhip_filter_extreme_counts(ptr(c), i64(c.size), f64(level), None))
+    if c is not counts:
+        counts[...] = c
+    return counts
+
+
+def box_sum_counts(counts, npix_super):
+    """weighting.py:229-254: (2 npix_super + 1)^2 box sum with zero padding; identity when disabled."""
+    if npix_super is None or npix_super <= 0:
+        return counts
+    assert np.issubdtype(counts.dtype, np.floating), (
+        f"box_sum_counts requires a floating-point counts array; got dtype={counts.dtype}"
+    )
+    _lib.require_gpu()
+    c = as_c(counts, np.float64)
+    ncorr, nx, ny = c.shape
+    out = np.empty_like(c)
+    check(lib().pfbhip_box_sum_counts(ptr(c), i64(ncorr), i64(nx), i64(ny), i64(int(npix_super)), ptr(out)))
+    return out.astype(counts.dtype, copy=False)

@@ -68,6 +68,32 @@ def test_counts_and_weights():
     assert w0.max() <= wgt.max() + 1e-9
 
 
+def test_filter_and_box_sum_counts():
+    """/root/reference/tests/test_weighting.py:138-190 (identity when disabled, 3x3 known answers) and the
+    restatement on random grids; filter_extreme_counts against numpy's median."""
+    from pfb_imaging_amd.utils.weighting import box_sum_counts, filter_extreme_counts
+
+    rng = np.random.default_rng(0)
+    counts = rng.random((2, 16, 16))
+    assert box_sum_counts(counts, 0) is counts and box_sum_counts(counts, -3) is counts
+    assert box_sum_counts(counts, None) is counts
+    c5 = np.arange(1.0, 26.0).reshape(1, 5, 5)
+    out = box_sum_counts(c5, 1)
+    assert out[0, 2, 2] == pytest.approx(117.0) and out[0, 0, 0] == pytest.approx(16.0)
+    assert out[0, 0, 2] == pytest.approx(33.0) and out.shape == c5.shape and out.dtype == c5.dtype
+    big = rng.random((2, 70, 53)) * (rng.random((2, 70, 53)) > 0.4)
+    for s in (1, 3):
+        np.testing.assert_allclose(box_sum_counts(big, s), ow.box_sum_counts(big, s), rtol=1e-13, atol=1e-13)
+    for level in (10.0, 3.0):
+        a, b = big.copy(), big.copy()
+        ra = filter_extreme_counts(a, level)
+        assert ra is a
+        np.testing.assert_array_equal(a, ow.filter_extreme_counts(b, level))
+    z = np.zeros((1, 4, 4))
+    assert not filter_extreme_counts(z, 10.0).any()
+    assert filter_extreme_counts(big, 0) is big
+
+
 def test_grid_partition_golden(golden_dir):
     """grid_partition on the reference's synthetic partition (test_imager_pass2.py:10-43) against the
     committed DFT dirty / PSF, plus shape / WSUM / PSFHAT checks."""
