@@ -28,7 +28,6 @@
 #include "common.hpp"
 #include "devcg.hpp"
 #include "eskernel.hpp"
-#include "gridder_kernels.hpp"
 #include "gridder_kernels_mp.hpp"
 #include "vismap.hpp"
 
@@ -578,40 +577,27 @@ struct pfbhip_gridder {
         timer.end();
     }
 
-    template <int W>
-    static constexpr size_t lds_bytes()
-    {
-        constexpr int D = kernel_poly_degree_c(W);
-        static_assert(kernel_poly_degree_c(W) == kernel_poly_degree(W), "degree mismatch");
-        return (size_t(2) * tile_rows(W) * tile_stride(W) + size_t(W) * (D + 1)) * sizeof(double);
-    }
-    template <int W>
-    void launch_grid_w(int plane, const double2 *sval)
-    {
-        size_t lds = lds_bytes<W>();
-        uint32_t nblk = uint32_t(ceil_div(info.nwork, 8) * 8);
-        hipLaunchKernelGGL(k_grid<W>, dim3(nblk), dim3(GRID_THREADS), lds, stream, plane_args(plane), sval, d_grid.p);
-    }
-    template <int W>
-    void launch_degrid_w(int plane, double2 *sacc)
-    {
-        size_t lds = lds_bytes<W>();
-        uint32_t nblk = uint32_t(ceil_div(info.nwork, 8) * 8);
-        hipLaunchKernelGGL(k_degrid<W>, dim3(nblk), dim3(GRID_THREADS), lds, stream, plane_args(plane), d_grid.p,
-                           sacc);
-    }
     GroupArgs group_args(int plane0, int kp) const
     {
         GroupArgs ga;
         ga.a = plane_args(plane0);
         ga.kp = kp;
+        ga.kp_alloc = kp_max;
         for (int k = 0; k < KP_MAX; ++k)
             ga.coefk[k] = (info.wmode == 1 && k < kp) ? lagr_coef[size_t(plane0 + k)] : 1.0;
         ga.plane_stride = plane_stride;
         return ga;
     }
+    // dynamic LDS: kp_max tiles (re/im or interleaved complex) + the (W, D+1) kernel table
     template <int W>
-    static constexpr size_t lds_bytes_mp()
+    size_t lds_bytes_mp() const
+    {
+        constexpr int D = kernel_poly_degree_c(W);
+        static_assert(kernel_poly_degree_c(W) == kernel_poly_degree(W), "degree mismatch");
+        return (size_t(2) * size_t(kp_max) * tile_rows(W) * tile_stride(W) + size_t(W) * (D + 1)) * sizeof(double);
+    }
+    template <int W>
+    static constexpr size_t lds_bytes_mp_max()
     {
         constexpr int D = kernel_poly_degree_c(W);
         return (size_t(2) * KP_MAX * tile_rows(W) * tile_stride(W) + size_t(W) * (D + 1)) * sizeof(double);
@@ -622,7 +608,7 @@ struct pfbhip_gridder {
         static bool attr_set = false;
         if (!attr_set) {
             PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_mp<W>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp<W>())));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp_max<W>())));
             attr_set = true;
         }
         hipLaunchKernelGGL(k_grid_mp<W>, dim3(uint32_t(info.nwork)), dim3(MP_THREADS), lds_bytes_mp<W>(), stream,
@@ -634,7 +620,7 @@ struct pfbhip_gridder {
         static bool attr_set = false;
         if (!attr_set) {
             PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_degrid_mp<W>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp<W>())));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp_max<W>())));
             attr_set = true;
         }
         hipLaunchKernelGGL(k_degrid_mp<W>, dim3(uint32_t(info.nwork)), dim3(MP_THREADS), lds_bytes_mp<W>(), stream,
@@ -677,11 +663,7 @@ struct pfbhip_gridder {
                                            size_t(sp.nrows) * size_t(info.nv) * sizeof(double2), stream));
             timer.end();
             timer.begin(0);
-            if (kp_max > 1) {
-                PFB_W_DISPATCH(launch_grid_mp_w, p0, kp, sval);
-            } else {
-                PFB_W_DISPATCH(launch_grid_w, p0, sval);
-            }
+            PFB_W_DISPATCH(launch_grid_mp_w, p0, kp, sval);
             PFB_HIP(hipGetLastError());
             timer.end();
             for (int k = 0; k < kp; ++k) {
@@ -746,11 +728,7 @@ struct pfbhip_gridder {
                 fft_rows_A(true, k);
             }
             timer.begin(1);
-            if (kp_max > 1) {
-                PFB_W_DISPATCH(launch_degrid_mp_w, p0, kp, sacc);
-            } else {
-                PFB_W_DISPATCH(launch_degrid_w, p0, sacc);
-            }
+            PFB_W_DISPATCH(launch_degrid_mp_w, p0, kp, sacc);
             PFB_HIP(hipGetLastError());
             timer.end();
         }
@@ -1272,7 +1250,7 @@ int pfbhip_gridder_grid_plane(pfbhip_gridder *g, const double *vis_host, const d
             PFB_HIP(hipGetLastError());
             auto &info = g->info;
             switch (info.W) {
-#define PFB_CASE(w) case w: g->launch_grid_w<w>(int(plane), g->d_sval.p); break;
+#define PFB_CASE(w) case w: g->launch_grid_mp_w<w>(int(plane), 1, g->d_sval.p); break;
                 PFB_CASE(4) PFB_CASE(5) PFB_CASE(6) PFB_CASE(7) PFB_CASE(8) PFB_CASE(9) PFB_CASE(10) PFB_CASE(11)
                 PFB_CASE(12) PFB_CASE(13) PFB_CASE(14) PFB_CASE(15) PFB_CASE(16)
 #undef PFB_CASE

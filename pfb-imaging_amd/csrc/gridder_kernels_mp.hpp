@@ -1,4 +1,16 @@
-// gridder_kernels_mp.hpp -- multi-plane variants of the scatter / gather kernels.
+// gridder_kernels_mp.hpp -- the scatter / gather kernels (multi-plane).
+//
+// Mapping: one workgroup per work item, the (TILE+W-1)^2 footprint of the tile in LDS.  A wavefront
+// handles FOUR visibilities at a time, one per 16-lane DPP row.  Lane b of a row owns footprint column
+// b: it evaluates the v-kernel of tap b and the u-kernel of tap b (two Horner chains on per-lane
+// register coefficients -- no exp/sqrt), then walks the W x W footprint along wrapped diagonals: at
+// step i it holds the u-kernel value of row (b+i) mod 16, obtained by rotating the row's u-values one
+// lane per step with a DPP row_ror (a VALU move, no LDS traffic).  At every step the 16 lanes of a row
+// touch 16 different rows AND columns; with an even LDS row stride that is bank-conflict free.
+//   scatter (k_grid_mp):   LDS f64 atomics (ds_add_f64) into two planes (re, im) per w-plane, then the
+//                          tile is flushed to HBM with global f64 atomics (halo cells are shared by tiles);
+//   gather  (k_degrid_mp): the tile is loaded into LDS as interleaved complex (ds_read_b128 per tap),
+//                          per-lane partial sums, 4-step DPP row reduction.
 //
 // A visibility's W x W footprint (u- and v-kernel values, LDS addresses) is the same on every
 // w-plane it touches; only a scalar plane weight differs.  These kernels keep the tiles of up to
@@ -22,6 +34,7 @@ constexpr int MP_THREADS = 1024;
 struct GroupArgs {
     PlaneArgs a;             // a.plane = first plane of the group
     int kp;                  // planes in this group (1..KP_MAX)
+    int kp_alloc;            // planes the LDS allocation holds (the plan's planes per pass)
     double coefk[KP_MAX];    // wmode 1: Lagrange denominators of the group's planes
     size_t plane_stride;     // complex elements between consecutive planes of the uv-grid buffer
 };
@@ -66,7 +79,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_grid_mp(GroupArgs ga, const doub
     constexpr int LS = tile_stride(W);
     constexpr int LL = tile_rows(W) * LS;
     extern __shared__ double lds[];
-    double *wtab = lds + 2 * KP_MAX * LL;
+    double *wtab = lds + 2 * ga.kp_alloc * LL;
     const int kp = ga.kp;
 
     uint32_t item = blockIdx.x;
@@ -169,8 +182,8 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
     constexpr int LS = tile_stride(W);
     constexpr int LL = tile_rows(W) * LS;
     extern __shared__ double lds[];
-    double2 *tiles = reinterpret_cast<double2 *>(lds);  // KP_MAX tiles of LL complex
-    double *wtab = lds + 2 * KP_MAX * LL;
+    double2 *tiles = reinterpret_cast<double2 *>(lds);  // kp_alloc tiles of LL complex
+    double *wtab = lds + 2 * ga.kp_alloc * LL;
     const int kp = ga.kp;
 
     uint32_t item = blockIdx.x;
