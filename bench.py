@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-planes", type=int, default=2)
     ap.add_argument("--force", default=None, help="developer knob: 'sigma,W' pins the kernel row")
+    ap.add_argument("--verbosity", type=int, default=0)
     args = ap.parse_args()
 
     from pfb_imaging_amd import _lib
@@ -141,7 +142,7 @@ def main():
     t0 = time.time()
     g = Gridder(case["uvw"], case["freq"], case["mask"], npix_x=nx, npix_y=ny, pixsize_x=case["cell"],
                 pixsize_y=case["cell"], center_x=0.0, center_y=0.0, epsilon=args.epsilon, flip_u=False, flip_v=True,
-                flip_w=False, do_wgridding=True, divide_by_n=False, sigma_min=1.1, sigma_max=3.0,
+                flip_w=False, do_wgridding=True, divide_by_n=False, sigma_min=1.1, sigma_max=3.0, verbosity=args.verbosity,
                 force=None if args.force is None else (float(args.force.split(",")[0]), int(args.force.split(",")[1])))
     g.set_weights(case["wgt"])
     t_plan = time.time() - t0

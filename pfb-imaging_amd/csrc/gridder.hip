@@ -20,6 +20,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -107,7 +108,9 @@ __global__ void k_keys(MapArgs m, uint32_t *keys, uint32_t *idx)
         return;
     }
     VisPos p = vis_position(m, i);
-    keys[i] = tile_of(m, p.iu0, p.iv0);
+    uint32_t key = tile_of(m, p.iu0, p.iv0);
+    if (m.key_planes > 1) key = key * uint32_t(m.key_planes) + uint32_t(min(max(p.p0, 0), m.key_planes - 1));
+    keys[i] = key;
 }
 
 // tstart[t] = first sorted position whose key >= t  (t = 0..ntiles); tstart[ntiles] = nactive
@@ -494,6 +497,7 @@ struct pfbhip_gridder {
     DevBuf<uint8_t> d_mask;
     DevBuf<uint32_t> d_src;
     DevBuf<WorkItem> d_work;
+    std::vector<size_t> work_off, work_cnt;  // per group of kp_max planes: slice of d_work
     // scratch
     DevBuf<double2> d_grid, d_sval, d_sacc, d_vis;
     DevBuf<double> d_wgt, d_swgt, d_img, d_img2, d_beam;
@@ -553,8 +557,9 @@ struct pfbhip_gridder {
         a.pu = d_pu.p;
         a.pv = d_pv.p;
         a.pw = d_pw.p;
-        a.work = d_work.p;
-        a.nwork = uint32_t(info.nwork);
+        const size_t grp = work_off.size() > 1 ? size_t(plane / kp_max) : 0;
+        a.work = d_work.p + work_off[grp];
+        a.nwork = uint32_t(work_cnt[grp]);
         return a;
     }
 
@@ -611,8 +616,9 @@ struct pfbhip_gridder {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp_max<W>())));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_grid_mp<W>, dim3(uint32_t(info.nwork)), dim3(MP_THREADS), lds_bytes_mp<W>(), stream,
-                           group_args(plane0, kp), sval, d_grid.p);
+        GroupArgs ga = group_args(plane0, kp);
+        if (ga.a.nwork == 0) return;
+        hipLaunchKernelGGL(k_grid_mp<W>, dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga, sval, d_grid.p);
     }
     template <int W>
     void launch_degrid_mp_w(int plane0, int kp, double2 *sacc)
@@ -623,8 +629,9 @@ struct pfbhip_gridder {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp_max<W>())));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_degrid_mp<W>, dim3(uint32_t(info.nwork)), dim3(MP_THREADS), lds_bytes_mp<W>(), stream,
-                           group_args(plane0, kp), d_grid.p, sacc);
+        GroupArgs ga = group_args(plane0, kp);
+        if (ga.a.nwork == 0) return;
+        hipLaunchKernelGGL(k_degrid_mp<W>, dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga, d_grid.p, sacc);
     }
 #define PFB_W_DISPATCH(fn, ...)                                          \
     switch (info.W) {                                                    \
@@ -896,6 +903,13 @@ static void nm1_range(const pfbhip_gridder_params &p, double lshift, double mshi
 static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq, const uint8_t *mask)
 {
     auto &prm = g->prm;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {  // verbosity >= 1: wall-clock of the plan-creation phases
+        if (prm.verbosity < 1) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pfbhip] plan: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     PFB_REQUIRE(prm.nrow >= 0 && prm.nchan >= 1, "bad visibility shape (%lld, %lld)", (long long)prm.nrow,
                 (long long)prm.nchan);
     PFB_REQUIRE(prm.nx >= 2 && prm.ny >= 2 && prm.nx <= 65536 && prm.ny <= 65536, "bad image shape (%lld, %lld)",
@@ -968,6 +982,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         if (wlo > whi) wlo = whi = 0.0;  // everything masked
     }
 
+    lap("upload + w range");
     choose_kernel(g, wlo, whi, tmax);
     PFB_REQUIRE(info.nplanes >= 1 && info.nplanes < 100000, "unreasonable number of w-planes (%lld)",
                 (long long)info.nplanes);
@@ -993,7 +1008,18 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
                       info.lshift, info.mshift, info.nshift};
 
     // ---- tile sort of the unmasked visibilities ----
+    g->kp_max = int(std::min<int64_t>(KP_MAX, info.nplanes));
+    const int64_t ngroups = ceil_div(info.nplanes, g->kp_max);
+    // Wide fields (ES-kernel planes, P > W + planes per pass): a visibility touches only W of the P
+    // planes.  Sorting by (tile, first plane) makes the visibilities that touch a pass's planes a
+    // contiguous range per tile, so every pass gets its own, shorter work list.
+    const bool plane_sorted = prm.do_wgridding && info.wmode == 0 && info.nplanes > info.W + g->kp_max - 1 &&
+                              info.ntiles * info.nplanes < (int64_t(1) << 32) - 2;
+    m.key_planes = plane_sorted ? int(info.nplanes) : 1;
+    const int64_t nkeys = info.ntiles * m.key_planes;
     std::vector<WorkItem> work;
+    g->work_off.clear();
+    g->work_cnt.clear();
     info.nactive = 0;
     if (g->nvis > 0) {
         DevBuf<uint32_t> k_in(size_t(g->nvis)), k_out(size_t(g->nvis)), v_in(size_t(g->nvis)), v_out(size_t(g->nvis));
@@ -1005,21 +1031,36 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         DevBuf<char> tmp(tmp_bytes);
         PFB_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k_in.p, k_out.p, v_in.p, v_out.p, int(g->nvis), 0,
                                                    32, st));
-        DevBuf<uint32_t> d_tstart(size_t(info.ntiles) + 1);
-        hipLaunchKernelGGL(k_tile_start, blocks1d(info.ntiles + 1), dim3(256), 0, st, k_out.p, g->nvis,
-                           uint32_t(info.ntiles), d_tstart.p);
+        DevBuf<uint32_t> d_tstart(size_t(nkeys) + 1);
+        hipLaunchKernelGGL(k_tile_start, blocks1d(nkeys + 1), dim3(256), 0, st, k_out.p, g->nvis, uint32_t(nkeys),
+                           d_tstart.p);
         PFB_HIP(hipGetLastError());
-        std::vector<uint32_t> tstart(size_t(info.ntiles) + 1);
+        lap("keys + radix sort");
+        std::vector<uint32_t> tstart(size_t(nkeys) + 1);
         PFB_HIP(hipMemcpyAsync(tstart.data(), d_tstart.p, tstart.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PFB_HIP(hipStreamSynchronize(st));
-        info.nactive = tstart[size_t(info.ntiles)];
-        for (int64_t t = 0; t < info.ntiles; ++t)
-            for (uint32_t b = tstart[t]; b < tstart[t + 1]; b += CHUNK)
-                work.push_back(WorkItem{uint32_t(t), b, std::min<uint32_t>(b + CHUNK, tstart[t + 1]), 0});
-        // Longest-processing-time-first: heavy chunks are dispatched first, the many tiny ones of the
-        // sparse outer uv-plane fill the tail (the uv density is strongly peaked at the centre).
-        std::stable_sort(work.begin(), work.end(),
-                         [](const WorkItem &x, const WorkItem &y) { return (x.end - x.begin) > (y.end - y.begin); });
+        info.nactive = tstart[size_t(nkeys)];
+        lap("tile starts");
+        const int64_t P = m.key_planes;
+        for (int64_t grp = 0; grp < (plane_sorted ? ngroups : 1); ++grp) {
+            // planes [q, q + kp) are touched by visibilities whose first plane lies in [q - W + 1, q + kp - 1]
+            const int64_t q = grp * g->kp_max, kp = std::min<int64_t>(g->kp_max, info.nplanes - q);
+            const int64_t lo_p = plane_sorted ? std::max<int64_t>(0, q - info.W + 1) : 0;
+            const int64_t hi_p = plane_sorted ? std::min<int64_t>(P - 1, q + kp - 1) : 0;
+            const size_t first = work.size();
+            for (int64_t t = 0; t < info.ntiles; ++t) {
+                const uint32_t b0 = tstart[size_t(t * P + lo_p)], b1 = tstart[size_t(t * P + hi_p + 1)];
+                for (uint32_t b = b0; b < b1; b += CHUNK)
+                    work.push_back(WorkItem{uint32_t(t), b, std::min<uint32_t>(b + CHUNK, b1), 0});
+            }
+            // Longest-processing-time-first: heavy chunks are dispatched first, the many tiny ones of the
+            // sparse outer uv-plane fill the tail (the uv density is strongly peaked at the centre).
+            std::stable_sort(work.begin() + first, work.end(),
+                             [](const WorkItem &x, const WorkItem &y) { return (x.end - x.begin) > (y.end - y.begin); });
+            g->work_off.push_back(first);
+            g->work_cnt.push_back(work.size() - first);
+        }
+        lap("work lists");
         const size_t na1 = size_t(std::max<int64_t>(info.nactive, 1));
         g->d_pu.alloc(na1);
         g->d_pv.alloc(na1);
@@ -1032,11 +1073,16 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         }
         PFB_HIP(hipStreamSynchronize(st));
     }
+    if (g->work_off.empty()) {
+        g->work_off.push_back(0);
+        g->work_cnt.push_back(0);
+    }
     info.nwork = int64_t(work.size());
     g->d_work.alloc(std::max<size_t>(work.size(), 1));
     if (!work.empty())
         PFB_HIP(hipMemcpyAsync(g->d_work.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice, st));
 
+    lap("records");
     // ---- kernel polynomial table ----
     {
         double perr = 0.0;
@@ -1071,9 +1117,9 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
                        g->d_corr.p);
     PFB_HIP(hipGetLastError());
 
+    lap("kernel table + correction");
     // ---- scratch + FFT plans ----
     g->plane_stride = size_t(info.nu) * size_t(info.nv);
-    g->kp_max = int(std::min<int64_t>(KP_MAX, info.nplanes));
     g->d_grid.alloc(g->plane_stride * size_t(g->kp_max));
     g->d_img.alloc(size_t(npix));
     g->d_sval.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
@@ -1145,6 +1191,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     // rows of A outside the occupied spans are never written: clear the plane once
     PFB_HIP(hipMemsetAsync(g->d_grid.p, 0, g->d_grid.bytes(), st));
     PFB_HIP(hipStreamSynchronize(st));
+    lap("buffers + rocFFT plans");
     info.device_bytes = g->device_bytes();
 }
 

@@ -30,6 +30,7 @@ struct MapArgs {
     double dnu, dnv;  // (double) nu, nv
     int nu, nv;
     int ntv;          // tiles along v
+    int key_planes;   // 1: sort key = tile; P > 1: key = tile * P + first plane (wide fields, ES-kernel planes)
     double shift;     // 1 - W/2
     int W;
     int do_w;
