@@ -162,6 +162,11 @@ int pfbhip_gridder_profile_get(pfbhip_gridder *g, double *ms /* [PFBHIP_NSTAGES]
 int pfbhip_r2c_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1, double *out_host);
 int pfbhip_c2r_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1 /* lastsize */, double *out_host);
 
+/* Hand-written batched row FFT (the second-axis pass of the plane transform), exposed for tests and
+ * benchmarks: in-place transform of (nrows, n) complex doubles, n = m 2^a (m in 1,3,5), 1024 <= n <= 16384.
+ * ms_out (may be NULL) receives the device time per transform when reps > 1. */
+int pfbhip_debug_rowfft(double *data_host, int64_t n, int64_t nrows, int inverse, int reps, double *ms_out);
+
 /* ---- PSF-convolution operator family -------------------------------- */
 /*
  * One plan serves psf_convolve_slice/cube/fscube (operators/psf.py:8-96),

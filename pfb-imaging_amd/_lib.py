@@ -60,7 +60,7 @@ SYMBOLS = (
     "pfbhip_gridder_set_weights", "pfbhip_gridder_hessian", "pfbhip_gridder_hessian_dev",
     "pfbhip_gridder_degrid_dev", "pfbhip_gridder_grid_dev", "pfbhip_gridder_profile", "pfbhip_gridder_profile_get",
     "pfbhip_gridder_cg",
-    "pfbhip_r2c_2d", "pfbhip_c2r_2d",
+    "pfbhip_r2c_2d", "pfbhip_c2r_2d", "pfbhip_debug_rowfft",
     "pfbhip_psfconv_create", "pfbhip_psfconv_destroy", "pfbhip_psfconv_set_psfhat", "pfbhip_psfconv_set_beam",
     "pfbhip_psfconv_apply", "pfbhip_psfconv_apply_dev", "pfbhip_psfconv_cg",
     "pfbhip_uvcell_index", "pfbhip_compute_counts", "pfbhip_counts_divide", "pfbhip_box_sum_counts",

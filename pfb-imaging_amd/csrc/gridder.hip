@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -30,6 +31,7 @@
 #include "devcg.hpp"
 #include "eskernel.hpp"
 #include "gridder_kernels_mp.hpp"
+#include "rowfft_api.hpp"
 #include "vismap.hpp"
 
 namespace pfbhip {
@@ -322,12 +324,13 @@ __global__ void k_finalize_T(const double *accT, const double *corr, const doubl
 }
 
 // B (ny, nu) <- A (nu, nv): B[y][u] = A[u][wrap(y - ny/2, nv)] for occupied 32-row blocks of u, 0 elsewhere
-__global__ void k_a2b(ImgGeom g, const uint8_t *occ, const double2 *A, double2 *B)
+__global__ void k_a2b(ImgGeom g, const uint8_t *occ, const double2 *A, double2 *B, int write_zeros)
 {
     __shared__ double2 t[TP][TP + 1];
     const int u0 = blockIdx.x * TP, y0 = blockIdx.y * TP;
     const int hy = g.ny / 2;
     const bool on = occ[blockIdx.x] != 0;
+    if (!on && !write_zeros) return;  // the fused second pass treats unoccupied blocks as zero without reading them
     if (on) {
         for (int k = threadIdx.y; k < TP; k += blockDim.y) {
             int u = u0 + k, y = y0 + threadIdx.x;
@@ -513,6 +516,9 @@ struct pfbhip_gridder {
     std::vector<RowSpan> spans;
     int64_t occ_rows = 0;
     int kp_max = 1;              // planes scattered / gathered per pass (LDS holds kp_max tiles)
+    RowFFT rowfft_u;             // hand-written row FFT of length nu with fused pad / crop (if nu is supported)
+    bool fused = false;
+    size_t bstride = 0;          // complex elements per plane of d_gridB
     size_t plane_stride = 0;     // complex elements per plane of d_grid
     rocfft_plan fftB_fwd = nullptr, fftB_bwd = nullptr;  // ny rows of length nu
     rocfft_execution_info fft_info = nullptr;
@@ -678,18 +684,40 @@ struct pfbhip_gridder {
                 fft_rows_A(false, k);
                 timer.begin(4);
                 hipLaunchKernelGGL(k_a2b, tgrid(info.nu, prm.ny), dim3(TP, 8), 0, stream, geom, d_occ.p,
-                                   d_grid.p + size_t(k) * plane_stride, d_gridB.p);
+                                   d_grid.p + size_t(k) * plane_stride, d_gridB.p + (fused ? size_t(k) * bstride : 0),
+                                   fused ? 0 : 1);
                 PFB_HIP(hipGetLastError());
                 timer.end();
-                fft_rows_B(false);
-                timer.begin(4);
-                hipLaunchKernelGGL(k_crop_screen_T, dim3(uint32_t(ceil_div(prm.nx, 256)), uint32_t(prm.ny)), dim3(256),
-                                   0, stream, geom, d_gridB.p, prm.do_wgridding, wplanes[size_t(p)], p == 0 ? 1 : 0,
-                                   d_accT.p);
-                PFB_HIP(hipGetLastError());
+                if (!fused) {
+                    fft_rows_B(false);
+                    timer.begin(4);
+                    hipLaunchKernelGGL(k_crop_screen_T, dim3(uint32_t(ceil_div(prm.nx, 256)), uint32_t(prm.ny)),
+                                       dim3(256), 0, stream, geom, d_gridB.p, prm.do_wgridding, wplanes[size_t(p)],
+                                       p == 0 ? 1 : 0, d_accT.p);
+                    PFB_HIP(hipGetLastError());
+                    timer.end();
+                }
+            }
+            if (fused) {
+                timer.begin(2);
+                fused_fft_crop(rowfft_u, fused_geom(), d_occ.p, d_gridB.p, bstride, fused_planes(p0, kp), prm.do_wgridding,
+                               p0 == 0, d_accT.p, stream);
                 timer.end();
             }
         }
+    }
+
+    FusedGeom fused_geom() const
+    {
+        return FusedGeom{int(prm.nx), int(prm.ny), int(info.nu), prm.pixsize_x, prm.pixsize_y, info.lshift, info.mshift,
+                         info.nshift};
+    }
+    FusedPlanes fused_planes(int p0, int kp) const
+    {
+        FusedPlanes fp;
+        fp.kp = kp;
+        for (int k = 0; k < FUSED_MAXPLANES; ++k) fp.w[k] = k < kp ? wplanes[size_t(p0 + k)] : 0.0;
+        return fp;
     }
 
     // out = accT^T * corr [* beam] * scale + eta * x
@@ -719,17 +747,26 @@ struct pfbhip_gridder {
         if (info.nactive == 0 || info.nwork == 0) return;
         for (int p0 = 0; p0 < info.nplanes; p0 += kp_max) {
             const int kp = int(std::min<int64_t>(kp_max, info.nplanes - p0));
+            if (fused) {
+                timer.begin(2);
+                fused_pad_fft(rowfft_u, fused_geom(), d_occ.p, d_accT.p, fused_planes(p0, kp), prm.do_wgridding, d_gridB.p,
+                              bstride, stream);
+                timer.end();
+            }
             for (int k = 0; k < kp; ++k) {
                 const int p = p0 + k;
+                if (!fused) {
+                    timer.begin(3);
+                    hipLaunchKernelGGL(k_pad_screen_T, dim3(uint32_t(ceil_div(info.nu, 256)), uint32_t(prm.ny)),
+                                       dim3(256), 0, stream, geom, d_accT.p, prm.do_wgridding, wplanes[size_t(p)],
+                                       d_gridB.p);
+                    PFB_HIP(hipGetLastError());
+                    timer.end();
+                    fft_rows_B(true);
+                }
                 timer.begin(3);
-                hipLaunchKernelGGL(k_pad_screen_T, dim3(uint32_t(ceil_div(info.nu, 256)), uint32_t(prm.ny)), dim3(256),
-                                   0, stream, geom, d_accT.p, prm.do_wgridding, wplanes[size_t(p)], d_gridB.p);
-                PFB_HIP(hipGetLastError());
-                timer.end();
-                fft_rows_B(true);
-                timer.begin(3);
-                hipLaunchKernelGGL(k_b2a, tgrid(info.nu, info.nv), dim3(TP, 8), 0, stream, geom, d_occ.p, d_gridB.p,
-                                   d_grid.p + size_t(k) * plane_stride);
+                hipLaunchKernelGGL(k_b2a, tgrid(info.nu, info.nv), dim3(TP, 8), 0, stream, geom, d_occ.p,
+                                   d_gridB.p + (fused ? size_t(k) * bstride : 0), d_grid.p + size_t(k) * plane_stride);
                 PFB_HIP(hipGetLastError());
                 timer.end();
                 fft_rows_A(true, k);
@@ -1125,7 +1162,14 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     g->d_sval.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
     g->d_sacc.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
 
-    g->d_gridB.alloc(size_t(prm.ny) * size_t(info.nu));
+    // The hand-written row FFT with fused pad / crop (rowfft.hpp) is correct for nu = {1,3,5} x 2^a but, at
+    // one 640-thread workgroup per CU, latency-bound (27 us per 10240-point row vs rocFFT's 2 workgroups
+    // per CU): measured 21.7 ms per C2 apply against 21.1 ms with rocFFT + separate pad / crop kernels.
+    // It therefore stays opt-in (PFBHIP_FUSED_FFT=1) until it carries two rows per CU.
+    const char *fenv = std::getenv("PFBHIP_FUSED_FFT");
+    g->fused = fenv != nullptr && fenv[0] == '1' && g->rowfft_u.init(info.nu);
+    g->bstride = size_t(prm.ny) * size_t(info.nu);
+    g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
     g->d_accT.alloc(size_t(npix));
 
     // occupancy of 32-row blocks of the uv-plane: tile rows that hold work, plus the block their
@@ -1179,8 +1223,10 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         g->occ_rows += sp.nrows;
         g->spans.push_back(sp);
     }
-    g->fftB_fwd = make_rows(info.nu, prm.ny, true);
-    g->fftB_bwd = make_rows(info.nu, prm.ny, false);
+    if (!g->fused) {  // the hand-written fused row FFT replaces the second-axis rocFFT pass when nu is supported
+        g->fftB_fwd = make_rows(info.nu, prm.ny, true);
+        g->fftB_bwd = make_rows(info.nu, prm.ny, false);
+    }
     info.occ_rows = int32_t(g->occ_rows);
     PFB_ROCFFT(rocfft_execution_info_create(&g->fft_info));
     if (wmax) {
