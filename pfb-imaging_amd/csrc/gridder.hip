@@ -517,6 +517,7 @@ struct pfbhip_gridder {
     int64_t occ_rows = 0;
     int kp_max = 1;              // planes scattered / gathered per pass (LDS holds kp_max tiles)
     RowFFT rowfft_u;             // hand-written row FFT of length nu with fused pad / crop (if nu is supported)
+    RowFFT rowfft_v;             // hand-written row FFT of length nv for the occupied rows of A (if nv is supported)
     bool fused = false;
     size_t bstride = 0;          // complex elements per plane of d_gridB
     size_t plane_stride = 0;     // complex elements per plane of d_grid
@@ -574,8 +575,13 @@ struct pfbhip_gridder {
     {
         timer.begin(2);
         for (auto &sp : spans) {
-            void *buf[1] = {d_grid.p + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv)};
-            PFB_ROCFFT(rocfft_execute(forward ? sp.fwd : sp.bwd, buf, nullptr, fft_info));
+            double2 *rows = d_grid.p + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv);
+            if (rowfft_v.ok) {
+                rowfft_plain(rowfft_v.pl, rows, int(sp.nrows), !forward, stream);
+            } else {
+                void *buf[1] = {rows};
+                PFB_ROCFFT(rocfft_execute(forward ? sp.fwd : sp.bwd, buf, nullptr, fft_info));
+            }
         }
         timer.end();
     }
@@ -707,11 +713,8 @@ struct pfbhip_gridder {
         }
     }
 
-    FusedGeom fused_geom() const
-    {
-        return FusedGeom{int(prm.nx), int(prm.ny), int(info.nu), prm.pixsize_x, prm.pixsize_y, info.lshift, info.mshift,
-                         info.nshift};
-    }
+    FusedGeom fgeom;  // filled once by create_impl (fused path)
+    const FusedGeom &fused_geom() const { return fgeom; }
     FusedPlanes fused_planes(int p0, int kp) const
     {
         FusedPlanes fp;
@@ -1162,12 +1165,27 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     g->d_sval.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
     g->d_sacc.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
 
-    // The hand-written row FFT with fused pad / crop (rowfft.hpp) is correct for nu = {1,3,5} x 2^a but, at
-    // one 640-thread workgroup per CU, latency-bound (27 us per 10240-point row vs rocFFT's 2 workgroups
-    // per CU): measured 21.7 ms per C2 apply against 21.1 ms with rocFFT + separate pad / crop kernels.
-    // It therefore stays opt-in (PFBHIP_FUSED_FFT=1) until it carries two rows per CU.
+    // Plane transforms: hand-written row FFT (rowfft.hpp) where the padded sizes are of the form
+    // {1,3,5} x 2^a (every size grid_size() prefers), with the pad / crop / w-screen of the second axis
+    // fused into its load / store; rocFFT row plans otherwise.  PFBHIP_FUSED_FFT=0 / PFBHIP_ROWFFT=0
+    // force the rocFFT paths (used by the tests to keep both alive).
     const char *fenv = std::getenv("PFBHIP_FUSED_FFT");
-    g->fused = fenv != nullptr && fenv[0] == '1' && g->rowfft_u.init(info.nu);
+    const char *renv = std::getenv("PFBHIP_ROWFFT");
+    g->fused = !(fenv != nullptr && fenv[0] == '0') && g->rowfft_u.init(info.nu);
+    if (!(renv != nullptr && renv[0] == '0')) (void)g->rowfft_v.init(info.nv);
+    if (g->fused) {
+        FusedGeom &fg = g->fgeom;
+        fg.nx = int(prm.nx);
+        fg.ny = int(prm.ny);
+        fg.nu = int(info.nu);
+        fg.px = prm.pixsize_x;
+        fg.py = prm.pixsize_y;
+        fg.lshift = info.lshift;
+        fg.mshift = info.mshift;
+        fg.nshift = info.nshift;
+        if (prm.do_wgridding) fused_geom_fit(fg);
+        if (prm.verbosity > 0) fprintf(stderr, "[pfbhip] fused w-screen: n-1 polynomial with %d coefficients\n", fg.npoly);
+    }
     g->bstride = size_t(prm.ny) * size_t(info.nu);
     g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
     g->d_accT.alloc(size_t(npix));
@@ -1200,9 +1218,11 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     g->d_occ.alloc(size_t(nblk));
     PFB_HIP(hipMemcpyAsync(g->d_occ.p, occ.data(), occ.size(), hipMemcpyHostToDevice, st));
 
-    rocfft_setup_once();
     size_t wmax = 0;
+    bool any_rocfft = false;
     auto make_rows = [&](int64_t len, int64_t batch, bool forward) {
+        rocfft_setup_once();
+        any_rocfft = true;
         rocfft_plan pl = nullptr;
         size_t lengths[1] = {size_t(len)};
         PFB_ROCFFT(rocfft_plan_create(&pl, rocfft_placement_inplace,
@@ -1218,8 +1238,10 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         pfbhip_gridder::RowSpan sp;
         sp.row0 = r.first * TP;
         sp.nrows = std::min<int64_t>(r.second * TP, info.nu) - sp.row0;
-        sp.fwd = make_rows(info.nv, sp.nrows, true);
-        sp.bwd = make_rows(info.nv, sp.nrows, false);
+        if (!g->rowfft_v.ok) {
+            sp.fwd = make_rows(info.nv, sp.nrows, true);
+            sp.bwd = make_rows(info.nv, sp.nrows, false);
+        }
         g->occ_rows += sp.nrows;
         g->spans.push_back(sp);
     }
@@ -1228,16 +1250,18 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         g->fftB_bwd = make_rows(info.nu, prm.ny, false);
     }
     info.occ_rows = int32_t(g->occ_rows);
-    PFB_ROCFFT(rocfft_execution_info_create(&g->fft_info));
-    if (wmax) {
-        g->d_fftwork.alloc(wmax);
-        PFB_ROCFFT(rocfft_execution_info_set_work_buffer(g->fft_info, g->d_fftwork.p, wmax));
+    if (any_rocfft) {
+        PFB_ROCFFT(rocfft_execution_info_create(&g->fft_info));
+        if (wmax) {
+            g->d_fftwork.alloc(wmax);
+            PFB_ROCFFT(rocfft_execution_info_set_work_buffer(g->fft_info, g->d_fftwork.p, wmax));
+        }
+        PFB_ROCFFT(rocfft_execution_info_set_stream(g->fft_info, st));
     }
-    PFB_ROCFFT(rocfft_execution_info_set_stream(g->fft_info, st));
     // rows of A outside the occupied spans are never written: clear the plane once
     PFB_HIP(hipMemsetAsync(g->d_grid.p, 0, g->d_grid.bytes(), st));
     PFB_HIP(hipStreamSynchronize(st));
-    lap("buffers + rocFFT plans");
+    lap("buffers + FFT plans");
     info.device_bytes = g->device_bytes();
 }
 

@@ -15,27 +15,35 @@ namespace pfbhip {
 
 struct PlainLoad {
     const double2 *row;
-    __device__ __forceinline__ double2 operator()(int i) const { return row[i]; }
+    __device__ __forceinline__ double2 operator()(int i, int) const { return row[i]; }
 };
 struct PlainStore {
     double2 *row;
     __device__ __forceinline__ void operator()(int i, double2 v) const { row[i] = v; }
 };
 
-// MAXT bounds the workgroup size: it sets the register budget (512 threads -> 2 waves/SIMD -> 256
-// VGPRs, 768 -> 168, 1024 -> 128); the 16-complex-per-thread row needs ~150 to stay out of scratch.
-#ifndef RF_MINWAVES
-#define RF_MINWAVES 1
-#endif
-template <int MAXT>
-__global__ void __launch_bounds__(MAXT, (MAXT == 512 ? RF_MINWAVES : 1)) k_rowfft_plain(RowFFTPlan pl, double2 *data, int nrows, int inverse)
+// One row per workgroup, S::T threads; the register budget follows from the workgroup size
+// (512 threads -> 256 VGPRs, 640/768 -> 168, 1024 -> 128); the straight-line passes need ~165.
+// INV is a template parameter: a run-time direction costs 128 v_cndmask per row and 20 % of the rate.
+template <class S, bool INV>
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_plain(const double2 *tw, double2 *data, int nrows)
 {
     extern __shared__ double rf_lds[];
-    const int row = blockIdx.x;  // one row per workgroup
+    const int row = blockIdx.x;
     if (row >= nrows) return;
-    PlainLoad ld{data + size_t(row) * pl.N};
-    PlainStore st{data + size_t(row) * pl.N};
-    rf_row(pl, ld, st, inverse != 0, rf_lds);
+    PlainLoad ld{data + size_t(row) * S::N};
+    PlainStore st{data + size_t(row) * S::N};
+    rf_row<S>(tw, ld, st, INV, rf_lds);
+}
+
+// LDS beyond 64 KiB needs the opt-in attribute, once per kernel instantiation
+template <class Kern>
+static void rf_allow_lds(Kern kern, bool *done)
+{
+    if (*done) return;
+    PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    *done = true;
 }
 
 bool RowFFT::init(int64_t N)
@@ -62,28 +70,27 @@ void RowFFT::release()
     ok = false;
 }
 
+template <class S, bool INV>
+static void launch_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, hipStream_t stream)
+{
+    static bool attr = false;
+    rf_allow_lds(&k_rowfft_plain<S, INV>, &attr);
+    hipLaunchKernelGGL((k_rowfft_plain<S, INV>), dim3(uint32_t(nrows)), dim3(S::T), size_t(S::LDS_BYTES), stream,
+                       pl.twiddle, data_dev, nrows);
+}
+
 void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inverse, hipStream_t stream)
 {
-    const size_t lds = size_t(pl.N) * sizeof(double);
-    static bool attr = false;
-    if (!attr) {
-        const int maxlds = 16384 * int(sizeof(double));
-        PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft_plain<512>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-        PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft_plain<768>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-        PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft_plain<1024>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-        attr = true;
+    switch (pl.N) {
+#define RF_X(L, K)                                                                  \
+    case (L << K):                                                                  \
+        if (inverse) launch_plain<RfShape<L, K>, true>(pl, data_dev, nrows, stream); \
+        else launch_plain<RfShape<L, K>, false>(pl, data_dev, nrows, stream);        \
+        break;
+        RF_FOR_SHAPES(RF_X)
+#undef RF_X
+        default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);
     }
-    const int nblk = nrows;
-    const int inv = inverse ? 1 : 0;
-    if (pl.T <= 512)
-        hipLaunchKernelGGL(k_rowfft_plain<512>, dim3(nblk), dim3(pl.T), lds, stream, pl, data_dev, nrows, inv);
-    else if (pl.T <= 768)
-        hipLaunchKernelGGL(k_rowfft_plain<768>, dim3(nblk), dim3(pl.T), lds, stream, pl, data_dev, nrows, inv);
-    else
-        hipLaunchKernelGGL(k_rowfft_plain<1024>, dim3(nblk), dim3(pl.T), lds, stream, pl, data_dev, nrows, inv);
     PFB_HIP(hipGetLastError());
 }
 
@@ -91,18 +98,58 @@ void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inver
 // fused second-axis passes of the plane transform
 // ---------------------------------------------------------------------------------------
 
-__device__ __forceinline__ double fg_nm1(double l, double m)
-{
-    double r2 = l * l + m * m;
-    if (r2 <= 1.0) return -r2 / (1.0 + sqrt(1.0 - r2));
-    return -sqrt(r2 - 1.0) - 1.0;
-}
+// n - 1 + nshift at image pixel (ix, iy): polynomial in r2 where the field is narrow enough for
+// fused_geom_fit(), the numerically stable closed form otherwise
 __device__ __forceinline__ double fg_t(const FusedGeom &g, int ix, int iy)
 {
-    double l = g.lshift + double(ix - g.nx / 2) * g.px;
-    double m = g.mshift + double(iy - g.ny / 2) * g.py;
-    return fg_nm1(l, m) + g.nshift;
+    const double l = g.lshift + double(ix - g.nx / 2) * g.px;
+    const double m = g.mshift + double(iy - g.ny / 2) * g.py;
+    const double r2 = l * l + m * m;
+    if (g.npoly > 0) {
+        const double sv = r2 * g.za + g.zb;
+        double acc = g.pc[0];
+        for (int k = 1; k < g.npoly; ++k) acc = acc * sv + g.pc[k];
+        return acc + g.nshift;
+    }
+    if (r2 <= 1.0) return -r2 / (1.0 + sqrt(1.0 - r2)) + g.nshift;
+    return -sqrt(r2 - 1.0) - 1.0 + g.nshift;
 }
+
+// sin(2 pi r) and cos(2 pi r) for |r| <= 1/2 (the caller has removed the integer part): one fold to
+// |q| <= 1/4, then the Taylor polynomials on |x| <= pi/2 (truncation < 2e-17).  About half the
+// instructions of sincospi(), which repeats the range reduction and handles specials.
+__device__ __forceinline__ void fg_sincos2pi(double r, double &sn, double &cs)
+{
+    const bool fold = fabs(r) > 0.25;
+    const double q = fold ? copysign(0.5, r) - r : r;
+    const double x = q * 6.283185307179586476925286766559;
+    const double x2 = x * x;
+    double ps = 1.0 / 51090942171709440000.0;   // 21!
+    ps = 1.0 / 121645100408832000.0 - ps * x2;  // 19!
+    ps = 1.0 / 355687428096000.0 - ps * x2;     // 17!
+    ps = 1.0 / 1307674368000.0 - ps * x2;       // 15!
+    ps = 1.0 / 6227020800.0 - ps * x2;          // 13!
+    ps = 1.0 / 39916800.0 - ps * x2;            // 11!
+    ps = 1.0 / 362880.0 - ps * x2;              // 9!
+    ps = 1.0 / 5040.0 - ps * x2;                // 7!
+    ps = 1.0 / 120.0 - ps * x2;                 // 5!
+    ps = 1.0 / 6.0 - ps * x2;                   // 3!
+    sn = x - x * x2 * ps;
+    double pc = 1.0 / 1124000727777607680000.0;   // 22!
+    pc = 1.0 / 2432902008176640000.0 - pc * x2;   // 20!
+    pc = 1.0 / 6402373705728000.0 - pc * x2;      // 18!
+    pc = 1.0 / 20922789888000.0 - pc * x2;        // 16!
+    pc = 1.0 / 87178291200.0 - pc * x2;           // 14!
+    pc = 1.0 / 479001600.0 - pc * x2;             // 12!
+    pc = 1.0 / 3628800.0 - pc * x2;               // 10!
+    pc = 1.0 / 40320.0 - pc * x2;                 // 8!
+    pc = 1.0 / 720.0 - pc * x2;                   // 6!
+    pc = 1.0 / 24.0 - pc * x2;                    // 4!
+    pc = 0.5 - pc * x2;                           // 2!
+    const double c0 = 1.0 - x2 * pc;
+    cs = fold ? -c0 : c0;
+}
+
 // image column of uv-column u (-1: u lies in the zero padding)
 __device__ __forceinline__ int fg_ix(const FusedGeom &g, int u)
 {
@@ -112,56 +159,71 @@ __device__ __forceinline__ int fg_ix(const FusedGeom &g, int u)
     return -1;
 }
 
+// Row of B with the unoccupied 32-column blocks read as zero.  The occupancy of the thread's
+// elements is looked up once per workgroup (bit `slot` of mask), not once per element and plane: a
+// byte load in front of every row load doubles the latency of the load phase.
 struct OccLoad {
     const double2 *row;
-    const uint8_t *occ;
-    __device__ __forceinline__ double2 operator()(int u) const
+    uint32_t mask;
+    __device__ __forceinline__ double2 operator()(int u, int slot) const
     {
-        return occ[u >> 5] ? row[u] : make_double2(0.0, 0.0);
+        return ((mask >> slot) & 1u) ? row[u] : make_double2(0.0, 0.0);
     }
 };
 
-template <int MAXT>
-__global__ void __launch_bounds__(MAXT) k_fused_fft_crop(RowFFTPlan pl, FusedGeom g, const uint8_t *occ,
+template <class S>
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(const double2 *tw, FusedGeom g, const uint8_t *occ,
                                                           const double2 *B, size_t bstride, FusedPlanes planes,
                                                           int do_w, int first, double *accT)
 {
     extern __shared__ double rf_lds[];
     const int y = blockIdx.x;
     double *arow = accT + size_t(y) * g.nx;
+    uint32_t mask = 0;
+    rf_for_each_load<S>(int(threadIdx.x), [&](int u, int slot) { mask |= (occ[u >> 5] ? 1u : 0u) << slot; });
     for (int k = 0; k < planes.kp; ++k) {
-        OccLoad ld{B + size_t(k) * bstride + size_t(y) * g.nu, occ};
-        double re[RF_E], im[RF_E];
+        OccLoad ld{B + size_t(k) * bstride + size_t(y) * g.nu, mask};
+        double re[S::E], im[S::E];
         int t;
-        rf_row_compute(pl, ld, true, rf_lds, t, re, im);
+        rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
         const double wk = planes.w[k];
         const bool overwrite = first && k == 0;
+        // groups of four outputs: the running sums of the planes so far are requested first, the
+        // screens evaluated while they are in flight
 #pragma unroll
-        for (int e = 0; e < RF_E; ++e) {
-            const int u = rf_out_pos(pl, t, e);
-            const int ix = fg_ix(g, u);
-            if (ix >= 0) {
-                double r = im[e];  // inverse transform: value = (im, re)
-                if (do_w) {
-                    double ph = wk * fg_t(g, ix, y);
-                    ph -= rint(ph);
-                    double s, c;
-                    sincospi(2.0 * ph, &s, &c);
-                    r = im[e] * c + re[e] * s;  // Re( (im + i re) * (c - i s) )
-                }
-                arow[ix] = overwrite ? r : arow[ix] + r;
+        for (int e0 = 0; e0 < S::E; e0 += 4) {
+            double old[4];
+#pragma unroll
+            for (int e = e0; e < e0 + 4; ++e) {
+                const int ix = fg_ix(g, S::out_pos(t, e));
+                old[e - e0] = (ix >= 0 && !overwrite) ? arow[ix] : 0.0;
             }
-            if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the number of sincospi chains in flight
+#pragma unroll
+            for (int e = e0; e < e0 + 4; ++e) {
+                const int ix = fg_ix(g, S::out_pos(t, e));
+                if (ix >= 0) {
+                    double r = im[e];  // inverse transform: value = (im, re)
+                    if (do_w) {
+                        double ph = wk * fg_t(g, ix, y);
+                        ph -= rint(ph);
+                        double s, c;
+                        fg_sincos2pi(ph, s, c);
+                        r = im[e] * c + re[e] * s;  // Re( (im + i re) * (c - i s) )
+                    }
+                    arow[ix] = old[e - e0] + r;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // bound the number of sincos chains in flight
         }
     }
 }
 
 struct PadLoad {
     const double *drow;  // dcT row y
-    FusedGeom g;
+    const FusedGeom &g;   // the kernel argument itself (a copy would put the coefficient array in scratch)
     int y, do_w;
     double wk;
-    __device__ __forceinline__ double2 operator()(int u) const
+    __device__ __forceinline__ double2 operator()(int u, int) const
     {
         const int ix = fg_ix(g, u);
         if (ix < 0) return make_double2(0.0, 0.0);
@@ -170,13 +232,13 @@ struct PadLoad {
         double ph = wk * fg_t(g, ix, y);
         ph -= rint(ph);
         double s, c;
-        sincospi(2.0 * ph, &s, &c);
+        fg_sincos2pi(ph, s, c);
         return make_double2(val * c, val * s);
     }
 };
 
-template <int MAXT>
-__global__ void __launch_bounds__(MAXT) k_fused_pad_fft(RowFFTPlan pl, FusedGeom g, const uint8_t *occ,
+template <class S>
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const double2 *tw, FusedGeom g, const uint8_t *occ,
                                                          const double *dcT, FusedPlanes planes, int do_w, double2 *B,
                                                          size_t bstride)
 {
@@ -184,71 +246,130 @@ __global__ void __launch_bounds__(MAXT) k_fused_pad_fft(RowFFTPlan pl, FusedGeom
     const int y = blockIdx.x;
     for (int k = 0; k < planes.kp; ++k) {
         PadLoad ld{dcT + size_t(y) * g.nx, g, y, do_w, planes.w[k]};
-        double re[RF_E], im[RF_E];
+        double re[S::E], im[S::E];
         int t;
-        rf_row_compute(pl, ld, false, rf_lds, t, re, im);
+        rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
         double2 *brow = B + size_t(k) * bstride + size_t(y) * g.nu;
 #pragma unroll
-        for (int e = 0; e < RF_E; ++e) {
-            const int u = rf_out_pos(pl, t, e);
+        for (int e = 0; e < S::E; ++e) {
+            const int u = S::out_pos(t, e);
             if (occ[u >> 5]) brow[u] = make_double2(re[e], im[e]);
         }
     }
 }
 
-template <class K512, class K768, class K1024>
-static void set_lds_attr(K512 a, K768 b, K1024 c)
+void fused_geom_fit(FusedGeom &g)
 {
-    const int maxlds = 16384 * int(sizeof(double));
-    PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(a), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-    PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(b), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-    PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(c), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    g.npoly = 0;
+    // largest r2 over the image (a corner)
+    long double zmax = 0.0L;
+    for (int cx = 0; cx < 2; ++cx)
+        for (int cy = 0; cy < 2; ++cy) {
+            long double l = (long double)g.lshift + (long double)((cx ? g.nx - 1 : 0) - g.nx / 2) * (long double)g.px;
+            long double m = (long double)g.mshift + (long double)((cy ? g.ny - 1 : 0) - g.ny / 2) * (long double)g.py;
+            zmax = std::max(zmax, l * l + m * m);
+        }
+    if (!(zmax > 0.0L) || zmax > 0.5L) return;
+    auto f = [](long double z) { return -z / (1.0L + sqrtl(1.0L - z)); };  // sqrt(1 - z) - 1
+    // Chebyshev coefficients of f on [0, zmax] (s = 2 z / zmax - 1)
+    const int M = 64;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    std::vector<long double> fv(M), c(M, 0.0L);
+    for (int j = 0; j < M; ++j) fv[size_t(j)] = f(0.5L * zmax * (cosl(pi * (j + 0.5L) / M) + 1.0L));
+    for (int k = 0; k < M; ++k) {
+        long double acc = 0.0L;
+        for (int j = 0; j < M; ++j) acc += fv[size_t(j)] * cosl(pi * k * (j + 0.5L) / M);
+        c[size_t(k)] = acc * (k == 0 ? 1.0L : 2.0L) / M;
+    }
+    const long double fmax = fabsl(f(zmax));
+    int deg = -1;
+    for (int d = 1; d <= FUSED_MAXPOLY; ++d) {
+        long double tail = 0.0L;
+        for (int k = d + 1; k < M / 2; ++k) tail += fabsl(c[size_t(k)]);
+        if (tail <= 1e-17L * fmax) { deg = d; break; }
+    }
+    if (deg < 0) return;
+    // Chebyshev -> monomial in s:  T_0 = 1, T_1 = s, T_{k+1} = 2 s T_k - T_{k-1}
+    std::vector<long double> mono(size_t(deg + 1), 0.0L), t0(size_t(deg + 1), 0.0L), t1(size_t(deg + 1), 0.0L);
+    t0[0] = 1.0L;
+    t1[1] = 1.0L;
+    for (int k = 0; k <= deg; ++k) {
+        const std::vector<long double> &tk = k == 0 ? t0 : t1;
+        for (int i = 0; i <= deg; ++i) mono[size_t(i)] += c[size_t(k)] * tk[size_t(i)];
+        if (k >= 1) {
+            std::vector<long double> t2(size_t(deg + 1), 0.0L);
+            for (int i = 0; i < deg; ++i) t2[size_t(i + 1)] = 2.0L * t1[size_t(i)];
+            for (int i = 0; i <= deg; ++i) t2[size_t(i)] -= t0[size_t(i)];
+            t0 = t1;
+            t1 = t2;
+        }
+    }
+    FusedGeom trial = g;
+    trial.npoly = deg + 1;
+    trial.za = double(2.0L / zmax);
+    trial.zb = -1.0;
+    for (int i = 0; i <= deg; ++i) trial.pc[i] = double(mono[size_t(deg - i)]);
+    // verify in double arithmetic, as the kernel evaluates it
+    long double worst = 0.0L;
+    const int NS = 4097;
+    for (int j = 0; j < NS; ++j) {
+        const double z = double(zmax * j / (NS - 1));
+        const double sv = z * trial.za + trial.zb;
+        double acc = trial.pc[0];
+        for (int k = 1; k < trial.npoly; ++k) acc = fma(acc, sv, trial.pc[k]);
+        worst = std::max(worst, fabsl((long double)acc - f((long double)z)));
+    }
+    if (worst <= 4e-16L * fmax) g = trial;
+}
+
+template <class S>
+static void launch_crop(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev,
+                        size_t bstride, const FusedPlanes &planes, int do_w, bool first, double *accT_dev,
+                        hipStream_t stream)
+{
+    static bool attr = false;
+    rf_allow_lds(&k_fused_fft_crop<S>, &attr);
+    hipLaunchKernelGGL(k_fused_fft_crop<S>, dim3(uint32_t(g.ny)), dim3(S::T), size_t(S::LDS_BYTES), stream,
+                       pl.twiddle, g, occ_dev, B_dev, bstride, planes, do_w, first ? 1 : 0, accT_dev);
+}
+
+template <class S>
+static void launch_pad(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev,
+                       const FusedPlanes &planes, int do_w, double2 *B_dev, size_t bstride, hipStream_t stream)
+{
+    static bool attr = false;
+    rf_allow_lds(&k_fused_pad_fft<S>, &attr);
+    hipLaunchKernelGGL(k_fused_pad_fft<S>, dim3(uint32_t(g.ny)), dim3(S::T), size_t(S::LDS_BYTES), stream,
+                       pl.twiddle, g, occ_dev, dcT_dev, planes, do_w, B_dev, bstride);
 }
 
 void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev, size_t bstride,
                     const FusedPlanes &planes, int do_w, bool first, double *accT_dev, hipStream_t stream)
 {
-    static bool attr = false;
-    if (!attr) {
-        set_lds_attr(&k_fused_fft_crop<512>, &k_fused_fft_crop<768>, &k_fused_fft_crop<1024>);
-        attr = true;
+    switch (f.pl.N) {
+#define RF_X(L, K)                                                                                            \
+    case (L << K):                                                                                            \
+        launch_crop<RfShape<L, K>>(f.pl, g, occ_dev, B_dev, bstride, planes, do_w, first, accT_dev, stream); \
+        break;
+        RF_FOR_SHAPES(RF_X)
+#undef RF_X
+        default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", f.pl.N);
     }
-    const RowFFTPlan &pl = f.pl;
-    const size_t lds = size_t(pl.N) * sizeof(double);
-    dim3 grid(uint32_t(g.ny)), blk(uint32_t(pl.T));
-    const int fi = first ? 1 : 0;
-    if (pl.T <= 512)
-        hipLaunchKernelGGL(k_fused_fft_crop<512>, grid, blk, lds, stream, pl, g, occ_dev, B_dev, bstride, planes, do_w, fi,
-                           accT_dev);
-    else if (pl.T <= 768)
-        hipLaunchKernelGGL(k_fused_fft_crop<768>, grid, blk, lds, stream, pl, g, occ_dev, B_dev, bstride, planes, do_w, fi,
-                           accT_dev);
-    else
-        hipLaunchKernelGGL(k_fused_fft_crop<1024>, grid, blk, lds, stream, pl, g, occ_dev, B_dev, bstride, planes, do_w,
-                           fi, accT_dev);
     PFB_HIP(hipGetLastError());
 }
 
 void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev,
                    const FusedPlanes &planes, int do_w, double2 *B_dev, size_t bstride, hipStream_t stream)
 {
-    static bool attr = false;
-    if (!attr) {
-        set_lds_attr(&k_fused_pad_fft<512>, &k_fused_pad_fft<768>, &k_fused_pad_fft<1024>);
-        attr = true;
+    switch (f.pl.N) {
+#define RF_X(L, K)                                                                                    \
+    case (L << K):                                                                                    \
+        launch_pad<RfShape<L, K>>(f.pl, g, occ_dev, dcT_dev, planes, do_w, B_dev, bstride, stream); \
+        break;
+        RF_FOR_SHAPES(RF_X)
+#undef RF_X
+        default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", f.pl.N);
     }
-    const RowFFTPlan &pl = f.pl;
-    const size_t lds = size_t(pl.N) * sizeof(double);
-    dim3 grid(uint32_t(g.ny)), blk(uint32_t(pl.T));
-    if (pl.T <= 512)
-        hipLaunchKernelGGL(k_fused_pad_fft<512>, grid, blk, lds, stream, pl, g, occ_dev, dcT_dev, planes, do_w, B_dev,
-                           bstride);
-    else if (pl.T <= 768)
-        hipLaunchKernelGGL(k_fused_pad_fft<768>, grid, blk, lds, stream, pl, g, occ_dev, dcT_dev, planes, do_w, B_dev,
-                           bstride);
-    else
-        hipLaunchKernelGGL(k_fused_pad_fft<1024>, grid, blk, lds, stream, pl, g, occ_dev, dcT_dev, planes, do_w, B_dev,
-                           bstride);
     PFB_HIP(hipGetLastError());
 }
 

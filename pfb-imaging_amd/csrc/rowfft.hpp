@@ -2,7 +2,7 @@
 //
 // Why: the second axis of the plane transform runs on the cropped, transposed plane B (ny, nu).
 // With rocFFT that pass needs B materialised twice (pad/crop kernel + in-place transform).  This
-// kernel takes a LOAD functor (element index -> value) and a STORE functor (element index, value),
+// kernel takes a LOAD functor (element index, slot -> value) and a STORE functor (element index, value),
 // so "pad + w-screen" feeds the transform directly from the image and "crop + w-screen + accumulate"
 // consumes it directly into the image: B is read or written once, not three times.
 //
@@ -22,43 +22,50 @@
 
 namespace pfbhip {
 
-constexpr int RF_E = 16;        // complex elements per thread
-constexpr int RF_MAXPASS = 8;
+// Supported row lengths: N = LEAD * 2^K with (LEAD, K) in RF_FOR_SHAPES, i.e. 1024 <= N <= 16384 of
+// the forms 2^a, 3*2^a, 5*2^a.  Every shape is its own kernel instantiation: the pass sequence, N and
+// T are compile-time constants (straight-line code; a run-time radix switch costs ~60 more VGPRs and
+// 35 % of the throughput).
+#define RF_FOR_SHAPES(X) \
+    X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14) X(3, 9) X(3, 10) X(3, 11) X(3, 12) X(5, 8) X(5, 9) X(5, 10) X(5, 11)
+
+// complex elements per thread: 32 (T = N/32 threads per row) where that leaves room for TWO rows per
+// CU (registers: 10 waves of <= 168 VGPRs; LDS: 2 x N doubles), so that one row's butterflies overlap
+// the other row's LDS transposes; 16 otherwise.
+#ifndef RF_E32_MAXN
+#define RF_E32_MAXN 0
+#endif
+constexpr int rf_elems(int N) { return (N >= 4096 && N <= RF_E32_MAXN) ? 32 : 16; }
 
 struct RowFFTPlan {
-    int N = 0, T = 0, npass = 0;
-    int radix[RF_MAXPASS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int N = 0, T = 0, lead = 0, K = 0;
     const double2 *twiddle = nullptr;  // device table exp(-2 pi i k / N), k < N (filled by the owner of the plan)
 };
 
-// N = m * 2^a with m in {1, 3, 5}, 1024 <= N <= 16384, N % 16 == 0
+// radix of pass p of the power-of-two part 2^K (after the optional leading radix-3/5 pass)
+constexpr int rf_npass(int K) { return (K + 3) / 4; }
+constexpr int rf_radix(int K, int p)
+{
+    // 8: 16 16 | 9: 16 8 4 | 10: 16 16 4 | 11: 16 16 8 | 12: 16 16 16 | 13: 16 16 8 4 | 14: 16 16 16 4
+    return p == 0 ? 16
+         : p == 1 ? (K == 9 ? 8 : 16)
+         : p == 2 ? (K == 9 || K == 10 ? 4 : (K == 11 || K == 13 ? 8 : 16))
+                  : 4;
+}
+
 inline bool rowfft_make_plan(int64_t N, RowFFTPlan *p)
 {
-    if (N < 1024 || N > 16384 || (N % 16) != 0) return false;
-    int64_t pow2 = N, m = 1;
-    if (pow2 % 5 == 0) { m = 5; pow2 /= 5; }
-    else if (pow2 % 3 == 0) { m = 3; pow2 /= 3; }
-    if (pow2 & (pow2 - 1)) return false;
-    if (pow2 < 16) return false;
-    RowFFTPlan pl;
-    pl.N = int(N);
-    pl.T = int(N / RF_E);
-    if (pl.T > 1024) return false;
-    int np = 0;
-    if (m > 1) pl.radix[np++] = int(m);
-    while (pow2 > 1) {
-#ifdef RF_SMALLRADIX
-        int r = pow2 >= 4 ? 4 : int(pow2);
-#else
-        int r = pow2 >= 16 ? 16 : int(pow2);
-#endif
-        if (np >= RF_MAXPASS) return false;
-        pl.radix[np++] = r;
-        pow2 /= r;
+#define RF_X(L, KK)                      \
+    if (N == (int64_t(L) << KK)) {       \
+        p->N = int(N);                   \
+        p->T = int(N) / rf_elems(int(N)); \
+        p->lead = L;                     \
+        p->K = KK;                       \
+        return true;                     \
     }
-    pl.npass = np;
-    *p = pl;
-    return true;
+    RF_FOR_SHAPES(RF_X)
+#undef RF_X
+    return false;
 }
 
 #if defined(__HIPCC__)
@@ -189,59 +196,88 @@ __device__ __forceinline__ void dft<16>(double2 (&v)[16])
 
 __device__ __forceinline__ int rf_swz(int p) { return p ^ ((p >> 4) & 15); }
 
-// Transpose through LDS: every thread scatters its NE values to positions pos[e] (or skips pos < 0),
-// then gathers the standard layout {t + e T}.  src and dst may be the same array.
-template <int NE>
-__device__ __forceinline__ void rf_exchange(const double (&src)[NE], const int (&pos)[NE], double (&dst)[RF_E], int t,
-                                            int T, double *lds)
-{
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-        if (pos[e] >= 0) lds[rf_swz(pos[e])] = src[e];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < RF_E; ++e) dst[e] = lds[rf_swz(t + e * T)];
-    __syncthreads();
-}
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the
+// vector-memory counter, which would serialise the prefetched twiddle loads (and the previous row's
+// stores) with every LDS transpose.
+__device__ __forceinline__ void rf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // LDS transpose after a radix-R pass: slot i + s IT holds output dft_index<R>(s) of butterfly
 // j = t + i T, i.e. position expand(j) + dft_index<R>(s) Ns; afterwards slot e holds position t + e T.
-template <int R>
-__device__ __forceinline__ void rf_transpose(double (&a)[RF_E], int t, int T, int Ns, double *lds)
+// The row moves one component at a time (N doubles of LDS) or, DUAL, both at once (2 N doubles, half
+// the barriers).
+template <int R, int E, bool DUAL>
+__device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], int t, int T, int N, int Ns, double *lds)
 {
-    constexpr int IT = RF_E / R;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
+    constexpr int IT = E / R;
+    // write position of slot i + s IT (recomputed per component: E address registers are worth more
+    // than E integer operations)
+    auto wpos = [&](int i, int s) {
         const int j = t + i * T;
         const int k = j % Ns;
-        const int j0 = (j - k) * R + k;
+        return rf_swz((j - k) * R + k + dft_index<R>(s) * Ns);
+    };
+    if (DUAL) {
+        double *l2 = lds + N;
 #pragma unroll
-        for (int s = 0; s < R; ++s) lds[rf_swz(j0 + dft_index<R>(s) * Ns)] = a[i + s * IT];
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                const int p = wpos(i, s);
+                lds[p] = re[i + s * IT];
+                l2[p] = im[i + s * IT];
+            }
+        rf_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            re[e] = lds[rf_swz(t + e * T)];
+            im[e] = l2[rf_swz(t + e * T)];
+        }
+        rf_barrier();
+    } else {
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+            for (int s = 0; s < R; ++s) lds[wpos(i, s)] = re[i + s * IT];
+        rf_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e) re[e] = lds[rf_swz(t + e * T)];
+        rf_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+            for (int s = 0; s < R; ++s) lds[wpos(i, s)] = im[i + s * IT];
+        rf_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e) im[e] = lds[rf_swz(t + e * T)];
+        rf_barrier();
     }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < RF_E; ++e) a[e] = lds[rf_swz(t + e * T)];
-    __syncthreads();
 }
 
-// One power-of-two pass.  On entry slot e holds position t + e T of the current array; on exit the
-// same holds for the next array (after the LDS transpose).  The LAST pass skips the transpose and
-// leaves the outputs in the butterfly's own slot order: slot i + s IT holds position
-// t + (i + dft_index<R>(s) IT) T (the caller's store uses rf_last_slot).
-template <int R>
-__device__ __forceinline__ void rf_pass(double (&re)[RF_E], double (&im)[RF_E], int t, int T, int N, int Ns, bool last,
-                                        const double2 *__restrict__ tw, double *lds)
+// first twiddle exp(-2 pi i k / (Ns R)) of each of the thread's butterflies in a radix-R pass
+template <int R, int E>
+__device__ __forceinline__ void rf_load_twiddles(double2 (&w1)[E / R], int t, int T, int N, int Ns,
+                                                 const double2 *__restrict__ tw)
 {
-    constexpr int IT = RF_E / R;
+#pragma unroll
+    for (int i = 0; i < E / R; ++i) w1[i] = tw[((t + i * T) % Ns) * (N / (Ns * R))];
+}
+
+// The butterflies of one power-of-two pass, in place: on entry slot e holds position t + e T of the
+// current array; on exit slot i + s IT holds output dft_index<R>(s) of butterfly t + i T.  After the
+// LAST pass that is position t + (i + dft_index<R>(s) IT) T (the caller's store uses rf_last_slot).
+template <int R, int E>
+__device__ __forceinline__ void rf_butterflies(double (&re)[E], double (&im)[E], bool twiddle,
+                                               const double2 (&w1s)[E / R])
+{
+    constexpr int IT = E / R;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int j = t + i * T;
-        const int k = j % Ns;
         double2 v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = make_double2(re[i + q * IT], im[i + q * IT]);
-        if (Ns > 1) {
-            const double2 w1 = tw[k * (N / (Ns * R))];  // exp(-2 pi i k / (Ns R))
+        if (twiddle) {
+            const double2 w1 = w1s[i];
             double2 w = w1;
 #pragma unroll
             for (int q = 1; q < R; ++q) {
@@ -255,31 +291,28 @@ __device__ __forceinline__ void rf_pass(double (&re)[RF_E], double (&im)[RF_E], 
             re[i + s * IT] = v[s].x;
             im[i + s * IT] = v[s].y;
         }
-    }
-    if (!last) {
-        rf_transpose<R>(re, t, T, Ns, lds);
-        rf_transpose<R>(im, t, T, Ns, lds);
+        if (E > 16 && R >= 8) __builtin_amdgcn_sched_barrier(0);  // one wide butterfly in flight at a time
     }
 }
 
-// position (divided by T, minus t) held by slot e after the LAST pass of radix R
-__host__ __device__ constexpr int rf_last_slot(int R, int e)
+// position (divided by T, minus t) held by slot e = i + s IT after the LAST pass of radix R
+__host__ __device__ constexpr int rf_last_slot(int R, int E, int e)
 {
-    // slot e = i + s IT, IT = 16 / R  ->  i + dft_index<R>(s) IT
-    return R == 16 ? ((e >> 2) + 4 * (e & 3))
-                   : (R == 8 ? ((e & 1) + 2 * (((e >> 1) >> 1) + 4 * ((e >> 1) & 1))) : e);
+    const int IT = E / R, i = e % IT, s = e / IT;
+    const int d = R == 16 ? (s >> 2) + 4 * (s & 3) : (R == 8 ? (s >> 1) + 4 * (s & 1) : s);
+    return i + d * IT;
 }
 
-// Leading odd pass (radix M = 3 or 5, Ns = 1): N/M butterflies, ceil(16/M) per thread, inputs read
-// straight from the load functor; always followed by the LDS transpose.
-template <int M, class Load>
-__device__ __forceinline__ void rf_first_odd(double (&re)[RF_E], double (&im)[RF_E], int t, int T, int N, Load &ld,
+// Leading odd pass (radix M = 3 or 5, Ns = 1): N/M butterflies, ceil(E/M) per thread, inputs read
+// straight from the load functor, outputs written straight into the LDS transpose.
+template <int M, int E, bool DUAL, class Load>
+__device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], int t, int T, int N, Load &ld,
                                              bool inverse, double *lds)
 {
-    constexpr int IT = (RF_E + M - 1) / M;
+    constexpr int IT = (E + M - 1) / M;
     const int nbf = N / M;
-    double ore[IT * M], oim[IT * M];
-    int pos[IT * M];
+    double *l2 = lds + N;
+    double oim[DUAL ? 1 : IT * M];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int j = t + i * T;
@@ -287,86 +320,144 @@ __device__ __forceinline__ void rf_first_odd(double (&re)[RF_E], double (&im)[RF
         if (j < nbf) {
 #pragma unroll
             for (int q = 0; q < M; ++q) {
-                double2 x = ld(j + q * nbf);
+                double2 x = ld(j + q * nbf, i * M + q);
                 v[q] = inverse ? make_double2(x.y, x.x) : x;
             }
             dft<M>(v);
-        }
 #pragma unroll
-        for (int q = 0; q < M; ++q) {
-            ore[i * M + q] = v[q].x;
-            oim[i * M + q] = v[q].y;
-            pos[i * M + q] = j < nbf ? j * M + q : -1;
+            for (int q = 0; q < M; ++q) {
+                lds[rf_swz(j * M + q)] = v[q].x;
+                if (DUAL) l2[rf_swz(j * M + q)] = v[q].y;
+            }
+        }
+        if constexpr (!DUAL) {
+#pragma unroll
+            for (int q = 0; q < M; ++q) oim[i * M + q] = v[q].y;
         }
         // keep the scheduler from interleaving all butterflies' load functors (each may carry a
-        // sincospi chain): that blows the register budget of the 640-thread workgroup
-        __builtin_amdgcn_sched_barrier(0);
+        // sincospi chain): that blows the register budget
+        if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
-    rf_exchange<IT * M>(ore, pos, re, t, T, lds);
-    rf_exchange<IT * M>(oim, pos, im, t, T, lds);
+    rf_barrier();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        re[e] = lds[rf_swz(t + e * T)];
+        if (DUAL) im[e] = l2[rf_swz(t + e * T)];
+    }
+    rf_barrier();
+    if constexpr (!DUAL) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int j = t + i * T;
+            if (j < nbf) {
+#pragma unroll
+                for (int q = 0; q < M; ++q) lds[rf_swz(j * M + q)] = oim[i * M + q];
+            }
+        }
+        rf_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e) im[e] = lds[rf_swz(t + e * T)];
+        rf_barrier();
+    }
 }
 
-// position of the value left in slot e after the last pass
-__device__ __forceinline__ int rf_out_pos(const RowFFTPlan &pl, int t, int e)
+// Compile-time description of one supported row length.
+template <int LEAD_, int K_>
+struct RfShape {
+    static constexpr int LEAD = LEAD_, K = K_;
+    static constexpr int N = LEAD_ << K_, E = rf_elems(N), T = N / E;
+    static constexpr int NP = rf_npass(K_);
+    static constexpr int RLAST = rf_radix(K_, NP - 1);
+    // E = 32 shapes run two workgroups per CU and therefore transpose one component at a time
+#ifdef RF_NO_DUAL
+    static constexpr bool DUAL = false;
+#else
+    static constexpr bool DUAL = E == 16 && N * 16 <= 160 * 1024;
+#endif
+    static constexpr int LDS_BYTES = (DUAL ? 2 : 1) * N * int(sizeof(double));
+    static constexpr int WG_PER_CU = (2 * LDS_BYTES <= 160 * 1024 && 2 * T <= 1024) ? 2 : 1;
+    static constexpr int WAVES_PER_SIMD = (WG_PER_CU * ((T + 63) / 64) + 3) / 4;  // register budget = 512 / this
+    // position of the value left in slot e after the last pass
+    static __device__ __forceinline__ int out_pos(int t, int e) { return t + rf_last_slot(RLAST, E, e) * T; }
+};
+
+// Passes P.. of the power-of-two part; w1 holds the (already requested) twiddles of pass P.  The
+// twiddles of pass P + 1 are requested BEFORE the LDS transpose of pass P so that their L2 latency
+// hides behind it.
+template <class S, int P, int NS>
+__device__ __forceinline__ void rf_passes(double (&re)[S::E], double (&im)[S::E], int t,
+                                          const double2 *__restrict__ tw, double *lds,
+                                          const double2 (&w1)[S::E / rf_radix(S::K, P)])
 {
-    const int Rl = pl.radix[pl.npass - 1];
-    const int slot = Rl == 16 ? rf_last_slot(16, e) : (Rl == 8 ? rf_last_slot(8, e) : e);
-    return t + slot * pl.T;
+    constexpr int R = rf_radix(S::K, P);
+    rf_butterflies<R, S::E>(re, im, NS > 1, w1);
+    if constexpr (P + 1 < S::NP) {
+        constexpr int R2 = rf_radix(S::K, P + 1);
+        double2 w2[S::E / R2];
+        rf_load_twiddles<R2, S::E>(w2, t, S::T, S::N, NS * R, tw);
+        rf_transpose<R, S::E, S::DUAL>(re, im, t, S::T, S::N, NS, lds);
+        rf_passes<S, P + 1, NS * R>(re, im, t, tw, lds, w2);
+    }
 }
 
-// load -> passes; on return slot e holds the transform at position rf_out_pos(pl, t, e) as
+// load -> passes; on return slot e holds the transform at position S::out_pos(t, e) as
 // (re[e], im[e]) for the forward transform and as (im[e], re[e]) for the (unnormalised) inverse.
-template <class Load>
-__device__ __forceinline__ void rf_row_compute(const RowFFTPlan &pl, Load &ld, bool inverse, double *lds, int &t_out,
-                                               double (&re)[RF_E], double (&im)[RF_E])
+template <class S, class Load>
+__device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, Load &ld, bool inverse, double *lds,
+                                               int &t_out, double (&re)[S::E], double (&im)[S::E])
 {
     int t = threadIdx.x;
     // Opaque to the optimiser: otherwise every pass's (row-invariant) LDS and global addresses are
     // hoisted out of the caller's loops and kept live -- hundreds of VGPRs of loop invariants.
     asm volatile("" : "+v"(t));
     t_out = t;
-    const int T = pl.T, N = pl.N;
-    int Ns = 1, p = 0;
-    if (pl.radix[0] == 5) {
-        rf_first_odd<5>(re, im, t, T, N, ld, inverse, lds);
-        Ns = 5;
-        p = 1;
-    } else if (pl.radix[0] == 3) {
-        rf_first_odd<3>(re, im, t, T, N, ld, inverse, lds);
-        Ns = 3;
-        p = 1;
+    constexpr int R0 = rf_radix(S::K, 0);
+    double2 w0[S::E / R0] = {};
+    if constexpr (S::LEAD > 1) {
+        rf_load_twiddles<R0, S::E>(w0, t, S::T, S::N, S::LEAD, tw);
+        rf_first_odd<S::LEAD, S::E, S::DUAL>(re, im, t, S::T, S::N, ld, inverse, lds);
     } else {
 #pragma unroll
-        for (int e = 0; e < RF_E; ++e) {
-            double2 x = ld(t + e * T);
+        for (int e = 0; e < S::E; ++e) {
+            double2 x = ld(t + e * S::T, e);
             re[e] = inverse ? x.y : x.x;
             im[e] = inverse ? x.x : x.y;
         }
     }
-    for (; p < pl.npass; ++p) {
-        const bool last = p == pl.npass - 1;
-        const int R = pl.radix[p];
-#ifndef RF_SMALLRADIX
-        if (R == 16) rf_pass<16>(re, im, t, T, N, Ns, last, pl.twiddle, lds);
-        else if (R == 8) rf_pass<8>(re, im, t, T, N, Ns, last, pl.twiddle, lds);
-        else
-#endif
-        if (R == 4) rf_pass<4>(re, im, t, T, N, Ns, last, pl.twiddle, lds);
-        else rf_pass<2>(re, im, t, T, N, Ns, last, pl.twiddle, lds);
-        Ns *= R;
+    rf_passes<S, 0, S::LEAD>(re, im, t, tw, lds, w0);
+}
+
+// Calls f(pos, slot) for every element the load functor of rf_row_compute<S> will be asked for by
+// thread t, in the same order and with the same compile-time slot numbers (< 32).
+template <class S, class F>
+__device__ __forceinline__ void rf_for_each_load(int t, F &&f)
+{
+    if constexpr (S::LEAD > 1) {
+        constexpr int M = S::LEAD, IT = (S::E + M - 1) / M, nbf = S::N / M;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int j = t + i * S::T;
+            if (j < nbf) {
+#pragma unroll
+                for (int q = 0; q < M; ++q) f(j + q * nbf, i * M + q);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < S::E; ++e) f(t + e * S::T, e);
     }
 }
 
 // The whole row: load -> passes -> store.
-template <class Load, class Store>
-__device__ __forceinline__ void rf_row(const RowFFTPlan &pl, Load &ld, Store &st, bool inverse, double *lds)
+template <class S, class Load, class Store>
+__device__ __forceinline__ void rf_row(const double2 *__restrict__ tw, Load &ld, Store &st, bool inverse, double *lds)
 {
-    double re[RF_E], im[RF_E];
+    double re[S::E], im[S::E];
     int t;
-    rf_row_compute(pl, ld, inverse, lds, t, re, im);
+    rf_row_compute<S>(tw, ld, inverse, lds, t, re, im);
 #pragma unroll
-    for (int e = 0; e < RF_E; ++e)
-        st(rf_out_pos(pl, t, e), inverse ? make_double2(im[e], re[e]) : make_double2(re[e], im[e]));
+    for (int e = 0; e < S::E; ++e)
+        st(S::out_pos(t, e), inverse ? make_double2(im[e], re[e]) : make_double2(re[e], im[e]));
 }
 
 #endif  // __HIPCC__

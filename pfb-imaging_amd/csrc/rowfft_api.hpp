@@ -19,10 +19,18 @@ struct RowFFT {
 void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inverse, hipStream_t stream);
 
 // Geometry of the second-axis (u) pass of the gridder's plane transform.
+constexpr int FUSED_MAXPOLY = 20;
 struct FusedGeom {
     int nx, ny, nu;
     double px, py, lshift, mshift, nshift;
+    // n - 1 = sqrt(1 - r2) - 1 as a polynomial in s = r2 * za + zb in [-1, 1] (npoly coefficients, highest
+    // first); npoly = 0: evaluate the square root (wide fields).  Filled by fused_geom_fit().
+    int npoly = 0;
+    double za = 0.0, zb = 0.0;
+    double pc[FUSED_MAXPOLY + 1] = {};
 };
+// Fit the polynomial of g.pc over the field of view of g (absolute error <= 4e-16 max|n - 1|), or leave npoly = 0.
+void fused_geom_fit(FusedGeom &g);
 constexpr int FUSED_MAXPLANES = 4;
 struct FusedPlanes {
     int kp;

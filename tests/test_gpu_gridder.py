@@ -340,19 +340,32 @@ def test_handwritten_row_fft_matches_numpy():
 
 
 def test_fused_row_fft_path(monkeypatch):
-    """Opt-in plane transform with the hand-written row FFT (fused pad / crop): same results as the
-    default path, to rounding."""
+    """Default plane transform (hand-written row FFTs, fused pad / crop / w-screen with the polynomial
+    n-1, or its closed form for wide fields) against the rocFFT fallback (separate pad / crop kernels)
+    and against the oracle.  W = 15 at sigma = 1.25 divides by a kernel transform of ~1e-7 at the image
+    edge, so two correct FFTs (rounding ~1e-16) differ by up to ~1e-8 THERE; with ~170 planes summed the
+    L2 difference is 3e-10 (measured: both paths sit 3.0e-10 from the oracle's numpy FFT)."""
     from pfb_imaging_amd.wgridder import Gridder
 
-    c = make(nrow=2500, npix=1024, widen=8.0, zscale=0.02)  # nu = 1280 = 5 * 2^8
-    kw = dict(npix_x=c["nx"], npix_y=c["ny"], pixsize_x=c["cell"], pixsize_y=c["cell"], epsilon=1e-7, flip_v=True,
-              do_wgridding=True, divide_by_n=False, force=(1.25, 15))
-    g0 = Gridder(c["uvw"], c["freq"], c["mask"], **kw)
-    assert g0.info["nu"] == 1280
-    d0, v0 = g0.vis2dirty(c["vis"], c["wgt"]), g0.dirty2vis(c["x"])
-    g0.close()
-    monkeypatch.setenv("PFBHIP_FUSED_FFT", "1")
-    g1 = Gridder(c["uvw"], c["freq"], c["mask"], **kw)
-    d1, v1 = g1.vis2dirty(c["vis"], c["wgt"]), g1.dirty2vis(c["x"])
-    g1.close()
-    assert rel(d1, d0) < 1e-10 and rel(v1, v0) < 1e-10  # screens differ by FMA contraction (~1e-16 * w t)
+    for widen, zscale, tol in ((8.0, 0.02, 1e-10), (60.0, 1.0, 2e-9), (1150.0, 0.002, 2e-9)):
+        c = make(nrow=2500, npix=1024, widen=widen, zscale=zscale)  # nu = 1280 = 5 * 2^8
+        monkeypatch.delenv("PFBHIP_FUSED_FFT", raising=False)
+        monkeypatch.delenv("PFBHIP_ROWFFT", raising=False)
+        g1, kw, mask = gpu_plan(c, force=(1.25, 15))
+        assert g1.info["nu"] == 1280 and g1.info["nplanes"] < 200
+        d1, v1 = g1.vis2dirty(c["vis"], c["wgt"]), g1.dirty2vis(c["x"])
+        if widen == 8.0:  # 5 polynomial planes: cheap enough for the CPU oracle
+            o = oracle_plan(c, g1, {k: v for k, v in kw.items() if k != "force"}, mask)
+            assert rel(d1, o.vis2dirty(c["vis"], c["wgt"])) < tol and rel(v1, o.dirty2vis(c["x"])) < tol
+        g1.close()
+        monkeypatch.setenv("PFBHIP_FUSED_FFT", "0")
+        monkeypatch.setenv("PFBHIP_ROWFFT", "0")
+        g0, _, _ = gpu_plan(c, force=(1.25, 15))
+        d0, v0 = g0.vis2dirty(c["vis"], c["wgt"]), g0.dirty2vis(c["x"])
+        g0.close()
+        assert rel(d1, d0) < tol and rel(v1, v0) < tol
+        monkeypatch.setenv("PFBHIP_FUSED_FFT", "1")  # mixed: fused second axis, rocFFT first axis
+        g2, _, _ = gpu_plan(c, force=(1.25, 15))
+        d2 = g2.vis2dirty(c["vis"], c["wgt"])
+        g2.close()
+        assert rel(d2, d0) < tol
