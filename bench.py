@@ -31,6 +31,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+# stage timer -> the kernel it brackets (name as rocprofv3 lists it)
+KERNEL_OF = {"grid": "k_grid_mp", "degrid": "k_degrid_mp", "fft_rows": "k_rowfft_plain", "pad": "k_b2a", "crop": "k_a2b",
+             "fft_crop": "k_fused_fft_crop", "pad_fft": "k_fused_pad_fft"}
 
 
 def algorithmic_bytes(info, nx, ny, nrow, nactive):
@@ -43,17 +46,31 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
     b_grid = P * (12 * G + 3 * I)
     # Per-launch compulsory bytes of the PRUNED pipeline actually run: only the
     # occupied rows of the uv-plane A (nu,nv) are cleared / scattered / transformed, the second axis runs
-    # on the cropped, transposed plane B (ny,nu).  A launch = what the stage timers count.
+    # on the cropped, transposed plane B (ny,nu), of which only the occupied columns are read / written.
+    # A launch = what the stage timers count (include/pfbhip.h, PFBHIP_NSTAGES).
     occ = info["occ_rows"] / info["nu"]
     B = ny * info["nu"] * Sc
-    ppl = P / -(-P // 4)  # planes per scatter / gather launch (multi-plane kernels, up to 4)
+    ngroups = -(-P // 4)          # scatter / gather / fused second-axis launches per direction (<= 4 planes each)
+    ppl = P / ngroups             # planes per such launch
+    fused = bool(info.get("fft_mode", 0) & 2)
     per_launch = {
-        "fft": (occ * G + B),                         # one row-FFT pass: 1 read + 1 write (average of the A and B passes)
-        "grid": ppl * (occ * G + nactive * (Sc + 24)),   # per plane: occupied plane rows written once + records read
+        "grid": ppl * (occ * G + nactive * (Sc + 24)),    # per plane: occupied plane rows written once + records read
         "degrid": ppl * (occ * G + nactive * (Sc + 24)),  # per plane: occupied plane rows read once + records read
-        "pad_screen": (I + B + occ * B + occ * G) / 2,   # pad+screen (image -> B) and transpose+pad (B -> occupied A)
-        "crop_screen": (occ * (ny / info["nv"]) * G + B + (nx / info["nu"]) * B + 2 * I) / 2,  # A -> B, B -> image RMW
     }
+    if fused:
+        per_launch.update({
+            "fft_rows": 2 * occ * G,                                  # first axis, one plane: read + write of the occupied rows
+            "pad": occ * B + occ * G,                                 # B -> A transpose with zero padding, one plane
+            "crop": occ * (ny / info["nv"]) * G + occ * B,            # A -> B transpose with crop, one plane
+            "fft_crop": ppl * occ * B + I * (2 - 1 / ngroups),        # planes read once; image written (first group) or read+written
+            "pad_fft": I + ppl * occ * B,                             # image read once per launch; occupied columns written per plane
+        })
+    else:
+        per_launch.update({
+            "fft_rows": occ * G + B,                                  # one row-FFT pass: 1 read + 1 write (average of the A and B passes)
+            "pad": (I + B + occ * B + occ * G) / 2,                   # pad+screen (image -> B) and transpose+pad (B -> occupied A)
+            "crop": (occ * (ny / info["nv"]) * G + B + (nx / info["nu"]) * B + 2 * I) / 2,  # A -> B, B -> image RMW
+        })
     return b_vis + b_grid, per_launch
 
 
@@ -177,7 +194,7 @@ def main():
 
     if rank == 0:
         b_apply, per_launch = algorithmic_bytes(info, nx, ny, case["uvw"].shape[0], g.nactive)
-        dom = max((s for s in stages if s in per_launch), key=lambda s: stages[s][0])
+        dom = max((s for s in stages if s in per_launch and stages[s][1]), key=lambda s: stages[s][0])
         dom_ms, dom_calls = stages[dom]
         avg_ms = dom_ms / max(dom_calls, 1)
         achieved = per_launch[dom] / (avg_ms * 1e-3) / 1e9
@@ -207,12 +224,14 @@ def main():
             "config": {
                 "workload": wl, "bands": world, "w_scheme": "polynomial planes" if info["wmode"] == 1 else "ES-kernel planes", "vis_per_band": int(case["uvw"].shape[0] * case["freq"].size),
                 "active_vis_per_band": int(g.nactive), "image": [nx, ny], "epsilon": args.epsilon,
-                "grid": [info["nu"], info["nv"]], "w_planes": info["nplanes"], "kernel_support": info["W"],
+                "grid": [info["nu"], info["nv"]], "occupied_rows": info["occ_rows"], "w_planes": info["nplanes"],
+                "kernel_support": info["W"], "plane_transform": ("own row FFT" if info["fft_mode"] & 1 else "rocFFT rows") +
+                (" + fused second axis" if info["fft_mode"] & 2 else " + rocFFT second axis"),
                 "sigma": info["sigma"], "parallelism": f"band-per-gpu x{world}" + (" + RCCL reduce" if world > 1 else ""),
                 "plan_seconds": round(t_plan, 2),
             },
             "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "alg_bytes_per_launch": per_launch[dom], "avg_launch_ms": avg_ms, "launches": dom_calls,
                 "apply_alg_bytes": b_apply,
@@ -223,6 +242,16 @@ def main():
                                        for s in per_launch if stages[s][1]},
             },
         }
+        if dom == "grid":
+            # The scatter kernel is bound by the LDS f64-atomic pipe, not by HBM:
+            # 2*16*16 ds_add_f64 lane-operations per visibility and plane, ~12 cycles per wave-instruction.
+            ngroups = -(-info["nplanes"] // 4)
+            winstr = g.nactive * (info["nplanes"] / ngroups) * 512 / 64          # wave-instructions per launch
+            floor_ms = winstr / 256 * 12 / 2.4e9 * 1e3                           # 256 CUs, 2.4 GHz
+            out["roofline"]["limiter"] = {
+                "bound": "lds_atomic", "wave_instr_per_launch": winstr, "cycles_per_instr": 12, "cus": 256,
+                "clock_ghz": 2.4, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
+            }
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(case, info, g.oracle_params(), args.cpu_planes)

@@ -103,6 +103,10 @@ typedef struct pfbhip_gridder_info {
     int32_t occ_rows;      /* rows of the uv-plane that hold visibilities (only these are cleared / transformed) */
     double wcenter, whalf;
     size_t device_bytes;   /* device memory held by the handle                */
+    /* plane transform: bit 0 = hand-written row FFT on the first axis (else rocFFT), bit 1 = second axis fused
+     * with pad / crop / w-screen (else rocFFT + separate kernels); both need sizes {1,3,5} x 2^a in 1024..16384 */
+    int32_t fft_mode;
+    int32_t screen_poly;   /* coefficients of the n-1 polynomial of the fused w-screen (0: closed form) */
 } pfbhip_gridder_info;
 
 int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw_host /* (nrow,3) */,
@@ -149,9 +153,13 @@ int pfbhip_gridder_degrid_dev(pfbhip_gridder *g, const double *dirty_dev, double
 int pfbhip_gridder_grid_dev(pfbhip_gridder *g, const double *vis_sorted_dev, double *dirty_dev);
 
 /* Per-stage device timing (HIP events on the handle's stream).  Stages:
- * 0 grid (scatter) 1 degrid (gather) 2 fft 3 pad+screen 4 crop+screen 5 other.
- * ms[s] = accumulated milliseconds, calls[s] = launches, since the last reset. */
-#define PFBHIP_NSTAGES 6
+ * 0 grid (scatter kernel)  1 degrid (gather kernel)  2 fft_rows (plain row-FFT passes: first axis, and the
+ * second axis on the rocFFT fallback)  3 pad (B -> A transpose; + pad/w-screen kernel on the fallback)
+ * 4 crop (A -> B transpose; + crop/w-screen kernel on the fallback)  5 other (clears, image transposes,
+ * scaling)  6 fft_crop (fused second-axis inverse FFT + crop + w-screen)  7 pad_fft (fused pad + w-screen +
+ * second-axis forward FFT).
+ * ms[s] = accumulated milliseconds, calls[s] = timed regions, since the last reset. */
+#define PFBHIP_NSTAGES 8
 int pfbhip_gridder_profile(pfbhip_gridder *g, int enable);
 int pfbhip_gridder_profile_get(pfbhip_gridder *g, double *ms /* [PFBHIP_NSTAGES] */, int64_t *calls, int reset);
 

@@ -17,8 +17,8 @@ i64 = ct.c_int64
 f64 = ct.c_double
 cint = ct.c_int
 vp = ct.c_void_p
-NSTAGES = 6
-STAGE_NAMES = ("grid", "degrid", "fft", "pad_screen", "crop_screen", "other")
+NSTAGES = 8
+STAGE_NAMES = ("grid", "degrid", "fft_rows", "pad", "crop", "other", "fft_crop", "pad_fft")
 UNIQUE_ID_BYTES = 128
 
 
@@ -38,6 +38,7 @@ class GridderInfo(ct.Structure):
         ("W", i32), ("tile", i32), ("beta", f64), ("sigma", f64), ("wmin", f64), ("dw", f64),
         ("nshift", f64), ("lshift", f64), ("mshift", f64), ("kernel_eps", f64),
         ("wmode", i32), ("occ_rows", i32), ("wcenter", f64), ("whalf", f64), ("device_bytes", ct.c_size_t),
+        ("fft_mode", i32), ("screen_poly", i32),
     ]
 
     def asdict(self):

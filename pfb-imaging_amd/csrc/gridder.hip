@@ -705,7 +705,7 @@ struct pfbhip_gridder {
                 }
             }
             if (fused) {
-                timer.begin(2);
+                timer.begin(6);
                 fused_fft_crop(rowfft_u, fused_geom(), d_occ.p, d_gridB.p, bstride, fused_planes(p0, kp), prm.do_wgridding,
                                p0 == 0, d_accT.p, stream);
                 timer.end();
@@ -751,7 +751,7 @@ struct pfbhip_gridder {
         for (int p0 = 0; p0 < info.nplanes; p0 += kp_max) {
             const int kp = int(std::min<int64_t>(kp_max, info.nplanes - p0));
             if (fused) {
-                timer.begin(2);
+                timer.begin(7);
                 fused_pad_fft(rowfft_u, fused_geom(), d_occ.p, d_accT.p, fused_planes(p0, kp), prm.do_wgridding, d_gridB.p,
                               bstride, stream);
                 timer.end();
@@ -852,39 +852,62 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
         } else {
             if (r.sigma < prm.sigma_min - 1e-9 || r.sigma > prm.sigma_max + 1e-9 || r.eps_max > eps1) continue;
         }
-        int64_t nu = grid_size(prm.nx, r.sigma), nv = grid_size(prm.ny, r.sigma);
-        for (int mode = 0; mode < (wgrid ? 2 : 1); ++mode) {
-            if (wgrid && prm.force_wmode != 0 && prm.force_wmode != mode + 1) continue;
-            double dw = 1.0;
-            int64_t npl = 1, touched = 1;
-            if (wgrid) {
-                if (mode == 0) {
-                    dw = 0.5 / r.sigma / tmax;
-                    npl = int64_t((whi - wlo) / dw + r.W);
-                    touched = r.W;
-                } else {
-                    // The interpolation bound is a max-norm bound attained only at the extreme pixel and
-                    // extreme w; its L2 average over the image and the w distribution is ~0.3x.  It gets
-                    // 2/3 of epsilon: max-norm identities at the phase centre (kernel error ~0 there) still
-                    // hold to epsilon, and the L2 total (2 kernels at ~eps/13 each + ~0.2 eps) stays << epsilon.
-                    npl = poly_planes_needed(2.0 * pi * 0.5 * (whi - wlo) * tmax, 2.0 * eps1);
-                    if (npl == 0) continue;
-                    touched = npl;
+        // Candidate grids: the smallest 2-3-5-7-smooth size >= sigma n, and the smallest size the
+        // hand-written row FFT supports ({1,3,5} x 2^a) if that stays within sigma_max -- a larger grid
+        // with the same (W, beta) only lowers the aliasing error.
+        int64_t cand_u[2] = {grid_size(prm.nx, r.sigma), rowfft_size_at_least(double(prm.nx) * r.sigma)};
+        int64_t cand_v[2] = {grid_size(prm.ny, r.sigma), rowfft_size_at_least(double(prm.ny) * r.sigma)};
+        for (int cand = 0; cand < 2; ++cand) {
+            const int64_t nu = cand_u[cand], nv = cand_v[cand];
+            if (nu <= 0 || nv <= 0) continue;
+            if (cand == 1 && (nu == cand_u[0] && nv == cand_v[0])) continue;
+            if (cand == 1 && prm.force_W <= 0 &&
+                (double(nu) > prm.sigma_max * double(prm.nx) || double(nv) > prm.sigma_max * double(prm.ny)))
+                continue;
+            RowFFTPlan tmp;
+            const bool own = rowfft_make_plan(nu, &tmp) && rowfft_make_plan(nv, &tmp);
+            for (int mode = 0; mode < (wgrid ? 2 : 1); ++mode) {
+                if (wgrid && prm.force_wmode != 0 && prm.force_wmode != mode + 1) continue;
+                double dw = 1.0;
+                int64_t npl = 1, touched = 1;
+                if (wgrid) {
+                    if (mode == 0) {
+                        dw = 0.5 / r.sigma / tmax;  // the w axis keeps the oversampling the kernel row was designed for
+                        npl = int64_t((whi - wlo) / dw + r.W);
+                        touched = r.W;
+                    } else {
+                        // The interpolation bound is a max-norm bound attained only at the extreme pixel and
+                        // extreme w; its L2 average over the image and the w distribution is ~0.3x.  It gets
+                        // 2/3 of epsilon: max-norm identities at the phase centre (kernel error ~0 there) still
+                        // hold to epsilon, and the L2 total (2 kernels at ~eps/13 each + ~0.2 eps) stays << epsilon.
+                        npl = poly_planes_needed(2.0 * pi * 0.5 * (whi - wlo) * tmax, 2.0 * eps1);
+                        if (npl == 0) continue;
+                        touched = npl;
+                    }
                 }
-            }
-            // per plane and direction: one FFT + ~3 streaming passes over the plane (memset/pad, crop, tile
-            // flush) at ~5 TB/s; scatter/gather ~ (fixed + W^2 taps) per visibility per touched plane.
-            double plane_cost = fft2d_seconds(nu, nv) + 3.0 * 16.0 * double(nu) * double(nv) / 5.0e12;
-            double gridcost = nvis * double(std::min<int64_t>(touched, npl)) * (40.0 + double(r.W * r.W)) * 0.6e-12;
-            double cost = double(npl) * plane_cost + gridcost;
-            if (cost < best_cost) {
-                best_cost = cost;
-                best = &r;
-                bnu = nu;
-                bnv = nv;
-                bnpl = npl;
-                bdw = dw;
-                bmode = mode;
+                // Cost of one Hessian apply (both directions), from the C2 / C5 profiles (profiles/r01g_*):
+                //  plane transform, per plane: hand-written row FFTs + fused second axis 2.7e-11 s per grid
+                //  point; rocFFT rows + separate pad / crop kernels = measured 2-D transform time + three
+                //  streaming passes at 5 TB/s;
+                //  scatter + gather: 0.30 ns per visibility and touched plane, independent of W <= 16 (the
+                //  diagonal walk always takes 16 steps of LDS atomics / reads).
+                const double plane_cost = own ? 2.7e-11 * double(nu) * double(nv)
+                                              : fft2d_seconds(nu, nv) + 3.0 * 16.0 * double(nu) * double(nv) / 5.0e12;
+                const double gridcost = nvis * double(std::min<int64_t>(touched, npl)) * 0.30e-9;
+                const double cost = double(npl) * plane_cost + gridcost;
+                // cheapest wins; within 1 % the more accurate row does (W is free up to 16, so the best row
+                // that maps to the same grid and plane count usually beats the requested epsilon)
+                const bool better = best == nullptr || cost < 0.99 * best_cost ||
+                                    (cost <= 1.01 * best_cost && r.eps_max < best->eps_max);
+                if (better) {
+                    best_cost = std::min(cost, best_cost);
+                    best = &r;
+                    bnu = nu;
+                    bnv = nv;
+                    bnpl = npl;
+                    bdw = dw;
+                    bmode = mode;
+                }
             }
         }
     }
@@ -1186,6 +1209,8 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         if (prm.do_wgridding) fused_geom_fit(fg);
         if (prm.verbosity > 0) fprintf(stderr, "[pfbhip] fused w-screen: n-1 polynomial with %d coefficients\n", fg.npoly);
     }
+    info.fft_mode = (g->rowfft_v.ok ? 1 : 0) | (g->fused ? 2 : 0);
+    info.screen_poly = g->fused ? g->fgeom.npoly : 0;
     g->bstride = size_t(prm.ny) * size_t(info.nu);
     g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
     g->d_accT.alloc(size_t(npix));

@@ -171,12 +171,15 @@ struct OccLoad {
     }
 };
 
+// lds_row: the kernel keeps the running sum over the launch's planes of its image row in LDS (nx doubles
+// behind the transpose buffer) and touches accT once; otherwise (no room) every plane read-modify-writes accT.
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(const double2 *tw, FusedGeom g, const uint8_t *occ,
                                                           const double2 *B, size_t bstride, FusedPlanes planes,
-                                                          int do_w, int first, double *accT)
+                                                          int do_w, int first, int lds_row, double *accT)
 {
     extern __shared__ double rf_lds[];
+    double *acc = rf_lds + S::LDS_BYTES / sizeof(double);
     const int y = blockIdx.x;
     double *arow = accT + size_t(y) * g.nx;
     uint32_t mask = 0;
@@ -187,16 +190,26 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
         int t;
         rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
         const double wk = planes.w[k];
-        const bool overwrite = first && k == 0;
-        // groups of four outputs: the running sums of the planes so far are requested first, the
-        // screens evaluated while they are in flight
+        const bool last = k == planes.kp - 1;
+        // what must be added to this plane's value: the LDS running sum (thread-private cells, no barrier)
+        // and / or the image so far
+        const bool add_lds = lds_row && k > 0;
+        const bool add_img = lds_row ? (last && !first) : !(first && k == 0);
+        const bool to_img = !lds_row || last;
+        // groups of four outputs: the running sums are requested first, the screens evaluated while they
+        // are in flight
 #pragma unroll
         for (int e0 = 0; e0 < S::E; e0 += 4) {
             double old[4];
 #pragma unroll
             for (int e = e0; e < e0 + 4; ++e) {
                 const int ix = fg_ix(g, S::out_pos(t, e));
-                old[e - e0] = (ix >= 0 && !overwrite) ? arow[ix] : 0.0;
+                double o = 0.0;
+                if (ix >= 0) {
+                    if (add_img) o = arow[ix];
+                    if (add_lds) o += acc[ix];
+                }
+                old[e - e0] = o;
             }
 #pragma unroll
             for (int e = e0; e < e0 + 4; ++e) {
@@ -210,7 +223,9 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
                         fg_sincos2pi(ph, s, c);
                         r = im[e] * c + re[e] * s;  // Re( (im + i re) * (c - i s) )
                     }
-                    arow[ix] = old[e - e0] + r;
+                    r += old[e - e0];
+                    if (to_img) arow[ix] = r;
+                    else acc[ix] = r;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);  // bound the number of sincos chains in flight
@@ -220,14 +235,21 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
 
 struct PadLoad {
     const double *drow;  // dcT row y
-    const FusedGeom &g;   // the kernel argument itself (a copy would put the coefficient array in scratch)
-    int y, do_w;
+    double *lrow;        // LDS copy of the row (NULL: none); plane 0 fills it, the others read it
+    const FusedGeom &g;  // the kernel argument itself (a copy would put the coefficient array in scratch)
+    int y, do_w, k;
     double wk;
     __device__ __forceinline__ double2 operator()(int u, int) const
     {
         const int ix = fg_ix(g, u);
         if (ix < 0) return make_double2(0.0, 0.0);
-        const double val = drow[ix];
+        double val;
+        if (lrow != nullptr && k > 0) {
+            val = lrow[ix];
+        } else {
+            val = drow[ix];
+            if (lrow != nullptr) lrow[ix] = val;  // thread-private cell: the same thread asks for it on every plane
+        }
         if (!do_w) return make_double2(val, 0.0);
         double ph = wk * fg_t(g, ix, y);
         ph -= rint(ph);
@@ -239,22 +261,24 @@ struct PadLoad {
 
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const double2 *tw, FusedGeom g, const uint8_t *occ,
-                                                         const double *dcT, FusedPlanes planes, int do_w, double2 *B,
-                                                         size_t bstride)
+                                                         const double *dcT, FusedPlanes planes, int do_w, int lds_row,
+                                                         double2 *B, size_t bstride)
 {
     extern __shared__ double rf_lds[];
+    double *lrow = lds_row ? rf_lds + S::LDS_BYTES / sizeof(double) : nullptr;
     const int y = blockIdx.x;
+    uint32_t omask = 0;  // occupancy of the thread's output columns
+#pragma unroll
+    for (int e = 0; e < S::E; ++e) omask |= (occ[S::out_pos(int(threadIdx.x), e) >> 5] ? 1u : 0u) << e;
     for (int k = 0; k < planes.kp; ++k) {
-        PadLoad ld{dcT + size_t(y) * g.nx, g, y, do_w, planes.w[k]};
+        PadLoad ld{dcT + size_t(y) * g.nx, lrow, g, y, do_w, k, planes.w[k]};
         double re[S::E], im[S::E];
         int t;
         rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
         double2 *brow = B + size_t(k) * bstride + size_t(y) * g.nu;
 #pragma unroll
-        for (int e = 0; e < S::E; ++e) {
-            const int u = S::out_pos(t, e);
-            if (occ[u >> 5]) brow[u] = make_double2(re[e], im[e]);
-        }
+        for (int e = 0; e < S::E; ++e)
+            if ((omask >> e) & 1u) brow[S::out_pos(t, e)] = make_double2(re[e], im[e]);
     }
 }
 
@@ -322,6 +346,10 @@ void fused_geom_fit(FusedGeom &g)
     if (worst <= 4e-16L * fmax) g = trial;
 }
 
+// The fused kernels transpose one component at a time (N doubles of LDS), which leaves room for the
+// workgroup's image row (nx doubles) when (N + nx) * 8 <= 160 KiB.
+static bool fused_row_fits(int N, int nx) { return (size_t(N) + size_t(nx)) * sizeof(double) <= 160 * 1024; }
+
 template <class S>
 static void launch_crop(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev,
                         size_t bstride, const FusedPlanes &planes, int do_w, bool first, double *accT_dev,
@@ -329,8 +357,10 @@ static void launch_crop(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t 
 {
     static bool attr = false;
     rf_allow_lds(&k_fused_fft_crop<S>, &attr);
-    hipLaunchKernelGGL(k_fused_fft_crop<S>, dim3(uint32_t(g.ny)), dim3(S::T), size_t(S::LDS_BYTES), stream,
-                       pl.twiddle, g, occ_dev, B_dev, bstride, planes, do_w, first ? 1 : 0, accT_dev);
+    const bool row = fused_row_fits(S::N, g.nx) && planes.kp > 1;
+    const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
+    hipLaunchKernelGGL(k_fused_fft_crop<S>, dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
+                       bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev);
 }
 
 template <class S>
@@ -339,17 +369,19 @@ static void launch_pad(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *
 {
     static bool attr = false;
     rf_allow_lds(&k_fused_pad_fft<S>, &attr);
-    hipLaunchKernelGGL(k_fused_pad_fft<S>, dim3(uint32_t(g.ny)), dim3(S::T), size_t(S::LDS_BYTES), stream,
-                       pl.twiddle, g, occ_dev, dcT_dev, planes, do_w, B_dev, bstride);
+    const bool row = fused_row_fits(S::N, g.nx) && planes.kp > 1;
+    const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
+    hipLaunchKernelGGL(k_fused_pad_fft<S>, dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
+                       planes, do_w, row ? 1 : 0, B_dev, bstride);
 }
 
 void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev, size_t bstride,
                     const FusedPlanes &planes, int do_w, bool first, double *accT_dev, hipStream_t stream)
 {
     switch (f.pl.N) {
-#define RF_X(L, K)                                                                                            \
-    case (L << K):                                                                                            \
-        launch_crop<RfShape<L, K>>(f.pl, g, occ_dev, B_dev, bstride, planes, do_w, first, accT_dev, stream); \
+#define RF_X(L, K)                                                                                                   \
+    case (L << K):                                                                                                   \
+        launch_crop<RfShape<L, K, false>>(f.pl, g, occ_dev, B_dev, bstride, planes, do_w, first, accT_dev, stream); \
         break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X
@@ -362,9 +394,9 @@ void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, 
                    const FusedPlanes &planes, int do_w, double2 *B_dev, size_t bstride, hipStream_t stream)
 {
     switch (f.pl.N) {
-#define RF_X(L, K)                                                                                    \
-    case (L << K):                                                                                    \
-        launch_pad<RfShape<L, K>>(f.pl, g, occ_dev, dcT_dev, planes, do_w, B_dev, bstride, stream); \
+#define RF_X(L, K)                                                                                           \
+    case (L << K):                                                                                           \
+        launch_pad<RfShape<L, K, false>>(f.pl, g, occ_dev, dcT_dev, planes, do_w, B_dev, bstride, stream); \
         break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X

@@ -68,6 +68,17 @@ inline bool rowfft_make_plan(int64_t N, RowFFTPlan *p)
     return false;
 }
 
+// smallest supported row length >= x (0 if none)
+inline int64_t rowfft_size_at_least(double x)
+{
+    int64_t best = 0;
+#define RF_X(L, KK)                                                       \
+    if (double(int64_t(L) << KK) >= x - 1e-9 && (best == 0 || (int64_t(L) << KK) < best)) best = int64_t(L) << KK;
+    RF_FOR_SHAPES(RF_X)
+#undef RF_X
+    return best;
+}
+
 #if defined(__HIPCC__)
 
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -194,6 +205,12 @@ __device__ __forceinline__ void dft<16>(double2 (&v)[16])
     }
 }
 
+// LDS address swizzle of the transposes (a bijection on [0, N), N % 16 == 0): the low four bits are
+// xored with bits 4..7, which spreads the stride-16 writes of the early passes over the banks.  The
+// counters still show ~45 % of the LDS cycles as bank conflicts at N = 10240 (the period-5 write
+// patterns); per-pass transforms that remove two thirds of them (rotation of the low five bits by p >> 5
+// for sub-lengths <= 5, none for the radix-5 exchange) were measured 2 % SLOWER: the transposes are not
+// on the critical path, the extra address arithmetic is.
 __device__ __forceinline__ int rf_swz(int p) { return p ^ ((p >> 4) & 15); }
 
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the
@@ -362,7 +379,7 @@ __device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], i
 }
 
 // Compile-time description of one supported row length.
-template <int LEAD_, int K_>
+template <int LEAD_, int K_, bool ALLOW_DUAL = true>
 struct RfShape {
     static constexpr int LEAD = LEAD_, K = K_;
     static constexpr int N = LEAD_ << K_, E = rf_elems(N), T = N / E;
@@ -372,10 +389,11 @@ struct RfShape {
 #ifdef RF_NO_DUAL
     static constexpr bool DUAL = false;
 #else
-    static constexpr bool DUAL = E == 16 && N * 16 <= 160 * 1024;
+    static constexpr bool DUAL = ALLOW_DUAL && E == 16 && N * 16 <= 160 * 1024;
 #endif
     static constexpr int LDS_BYTES = (DUAL ? 2 : 1) * N * int(sizeof(double));
-    static constexpr int WG_PER_CU = (2 * LDS_BYTES <= 160 * 1024 && 2 * T <= 1024) ? 2 : 1;
+    // (the fused kernels, ALLOW_DUAL = false, add their image row to the LDS: one workgroup per CU)
+    static constexpr int WG_PER_CU = (ALLOW_DUAL && 2 * LDS_BYTES <= 160 * 1024 && 2 * T <= 1024) ? 2 : 1;
     static constexpr int WAVES_PER_SIMD = (WG_PER_CU * ((T + 63) / 64) + 3) / 4;  // register budget = 512 / this
     // position of the value left in slot e after the last pass
     static __device__ __forceinline__ int out_pos(int t, int e) { return t + rf_last_slot(RLAST, E, e) * T; }

@@ -16,8 +16,9 @@ import json
 import sys
 
 STAGE_OF = [
-    ("k_grid", "grid"), ("k_degrid", "degrid"), ("fft_", "fft"), ("transpose_", "fft"),
-    ("k_pad_screen", "pad_screen"), ("k_b2a", "pad_screen"), ("k_crop_screen", "crop_screen"), ("k_a2b", "crop_screen"),
+    ("k_grid", "grid"), ("k_degrid", "degrid"), ("k_fused_fft_crop", "fft_crop"), ("k_fused_pad_fft", "pad_fft"),
+    ("k_rowfft_plain", "fft_rows"), ("fft_", "fft_rows"), ("transpose_", "fft_rows"),
+    ("k_pad_screen", "pad"), ("k_b2a", "pad"), ("k_crop_screen", "crop"), ("k_a2b", "crop"),
 ]
 
 
