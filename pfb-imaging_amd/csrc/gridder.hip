@@ -619,31 +619,53 @@ struct pfbhip_gridder {
         constexpr int D = kernel_poly_degree_c(W);
         return (size_t(2) * KP_MAX * tile_rows(W) * tile_stride(W) + size_t(W) * (D + 1)) * sizeof(double);
     }
-    template <int W>
-    void launch_grid_mp_w(int plane0, int kp, const double2 *sval)
+    template <int W, int KP>
+    void launch_grid_mp_wk(const GroupArgs &ga, const double2 *sval)
     {
         static bool attr_set = false;
         if (!attr_set) {
-            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_mp<W>),
+            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_mp<W, KP>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp_max<W>())));
             attr_set = true;
         }
+        hipLaunchKernelGGL((k_grid_mp<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga, sval,
+                           d_grid.p);
+    }
+    template <int W>
+    void launch_grid_mp_w(int plane0, int kp, const double2 *sval)
+    {
         GroupArgs ga = group_args(plane0, kp);
         if (ga.a.nwork == 0) return;
-        hipLaunchKernelGGL(k_grid_mp<W>, dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga, sval, d_grid.p);
+        switch (kp) {
+            case 1: launch_grid_mp_wk<W, 1>(ga, sval); break;
+            case 2: launch_grid_mp_wk<W, 2>(ga, sval); break;
+            case 3: launch_grid_mp_wk<W, 3>(ga, sval); break;
+            default: launch_grid_mp_wk<W, 4>(ga, sval); break;
+        }
+    }
+    template <int W, int KP>
+    void launch_degrid_mp_wk(const GroupArgs &ga, double2 *sacc)
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_degrid_mp<W, KP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp_max<W>())));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_degrid_mp<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga,
+                           d_grid.p, sacc);
     }
     template <int W>
     void launch_degrid_mp_w(int plane0, int kp, double2 *sacc)
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_degrid_mp<W>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp_max<W>())));
-            attr_set = true;
-        }
         GroupArgs ga = group_args(plane0, kp);
         if (ga.a.nwork == 0) return;
-        hipLaunchKernelGGL(k_degrid_mp<W>, dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga, d_grid.p, sacc);
+        switch (kp) {
+            case 1: launch_degrid_mp_wk<W, 1>(ga, sacc); break;
+            case 2: launch_degrid_mp_wk<W, 2>(ga, sacc); break;
+            case 3: launch_degrid_mp_wk<W, 3>(ga, sacc); break;
+            default: launch_degrid_mp_wk<W, 4>(ga, sacc); break;
+        }
     }
 #define PFB_W_DISPATCH(fn, ...)                                          \
     switch (info.W) {                                                    \

@@ -44,7 +44,9 @@ struct PlaneArgs {
 
 // value of lane (l -/+ 1) of the same 16-lane row (direction is irrelevant to the callers: they
 // rotate the tap index alongside the data)
-__device__ __forceinline__ int rot1_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false); }
+// (mov_dpp leaves the "old" operand undefined: every lane is written, and update_dpp(0, ...) costs a
+// v_mov to materialise the zero in front of every rotation)
+__device__ __forceinline__ int rot1_i32(int v) { return __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, false); }
 __device__ __forceinline__ double rot1_f64(double v)
 {
     int lo = rot1_i32(__double2loint(v)), hi = rot1_i32(__double2hiint(v));
@@ -53,8 +55,8 @@ __device__ __forceinline__ double rot1_f64(double v)
 template <int N>
 __device__ __forceinline__ double rotn_f64(double v)
 {
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + N, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + N, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 

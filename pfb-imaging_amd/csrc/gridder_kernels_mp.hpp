@@ -69,7 +69,10 @@ __device__ __forceinline__ double row_bcast_f64(double v, int k)
     return __shfl(v, src);
 }
 
-template <int W>
+// KP (planes of this launch) is a template parameter: with a run-time count every plane's LDS access
+// sits in its own basic block behind a branch, which serialises the gather (each ds_read_b128 was
+// followed by s_waitcnt lgkmcnt(0)) and costs the scatter a branch per atomic pair.
+template <int W, int KP>
 __global__ void __launch_bounds__(MP_THREADS) k_grid_mp(GroupArgs ga, const double2 *__restrict__ sval,
                                                          double2 *__restrict__ grid)
 {
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_grid_mp(GroupArgs ga, const doub
     constexpr int LL = tile_rows(W) * LS;
     extern __shared__ double lds[];
     double *wtab = lds + 2 * ga.kp_alloc * LL;
-    const int kp = ga.kp;
+    constexpr int kp = KP;
 
     uint32_t item = blockIdx.x;
     if (item >= a.nwork) return;
@@ -118,10 +121,10 @@ __global__ void __launch_bounds__(MP_THREADS) k_grid_mp(GroupArgs ga, const doub
             double ku = horner<D>(c, zu);
             const double kv = horner<D>(c, zv);
             const int lu = wrap_once((int)fu, a.nu) - bu, lv = wrap_once((int)fv, a.nv) - bv;
-            double vr[KP_MAX], vi[KP_MAX];
+            double vr[KP], vi[KP];
             bool touch = false;  // uniform over the 16-lane row
 #pragma unroll
-            for (int k = 0; k < KP_MAX; ++k) {
+            for (int k = 0; k < KP; ++k) {
                 const double kw = row_bcast_f64(kwl, k);
                 touch = touch || (kw != 0.0);
                 vr[k] = val.x * (kw * kv);
@@ -129,20 +132,21 @@ __global__ void __launch_bounds__(MP_THREADS) k_grid_mp(GroupArgs ga, const doub
             }
             const int colbase = lu * LS + lv + b;
             int arow = b;
+            int rowoff = b * LS;  // arow * LS, rotated alongside (one DPP move instead of a multiply-add per step)
             if (touch) {  // rows whose visibility touches no plane of the group (or is past the end) sit out
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int off = colbase + arow * LS;
+                    const int off = colbase + rowoff;
                     if (W >= 14 || (arow < W && b < W)) {
 #pragma unroll
-                        for (int k = 0; k < KP_MAX; ++k)
-                            if (k < kp) {
-                                unsafeAtomicAdd(&lds[(2 * k) * LL + off], vr[k] * ku);
-                                unsafeAtomicAdd(&lds[(2 * k + 1) * LL + off], vi[k] * ku);
-                            }
+                        for (int k = 0; k < KP; ++k) {
+                            unsafeAtomicAdd(&lds[(2 * k) * LL + off], vr[k] * ku);
+                            unsafeAtomicAdd(&lds[(2 * k + 1) * LL + off], vi[k] * ku);
+                        }
                     }
                     ku = rot1_f64(ku);
-                    arow = rot1_i32(arow);
+                    rowoff = rot1_i32(rowoff);
+                    if (W < 14) arow = rot1_i32(arow);
                 }
             }
         }
@@ -172,7 +176,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_grid_mp(GroupArgs ga, const doub
     }
 }
 
-template <int W>
+template <int W, int KP>
 __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const double2 *__restrict__ grid,
                                                            double2 *__restrict__ sacc)
 {
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
     extern __shared__ double lds[];
     double2 *tiles = reinterpret_cast<double2 *>(lds);  // kp_alloc tiles of LL complex
     double *wtab = lds + 2 * ga.kp_alloc * LL;
-    const int kp = ga.kp;
+    constexpr int kp = KP;
 
     uint32_t item = blockIdx.x;
     if (item >= a.nwork) return;
@@ -232,33 +236,65 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
             double ku = horner<D>(c, zu);
             const double kv = horner<D>(c, zv);
             const int lu = wrap_once((int)fu, a.nu) - bu, lv = wrap_once((int)fv, a.nv) - bv;
-            double kw[KP_MAX];
+            double kw[KP];
+            bool touch = false;
 #pragma unroll
-            for (int k = 0; k < KP_MAX; ++k) kw[k] = row_bcast_f64(kwl, k);
-            const bool touch = (kw[0] != 0.0) || (kw[1] != 0.0) || (kw[2] != 0.0) || (kw[3] != 0.0);
+            for (int k = 0; k < KP; ++k) {
+                kw[k] = row_bcast_f64(kwl, k);
+                touch = touch || (kw[k] != 0.0);
+            }
             const int colbase = lu * LS + lv + b;
             int arow = b;
-            double sr[KP_MAX] = {0.0, 0.0, 0.0, 0.0}, si[KP_MAX] = {0.0, 0.0, 0.0, 0.0};
+            double sr[KP], si[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) sr[k] = si[k] = 0.0;
             if (touch) {
+                if (W >= 14) {
+                    // software pipeline: the reads of step i + 1 are issued before the FMAs of step i; the
+                    // row offset arow * LS is rotated itself (one DPP move + one add per step)
+                    int rowoff = arow * LS;
+                    double2 cur[KP];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int off = colbase + arow * LS;
-                    if (W >= 14 || (arow < W && b < W)) {
+                    for (int k = 0; k < KP; ++k) cur[k] = tiles[k * LL + colbase + rowoff];
 #pragma unroll
-                        for (int k = 0; k < KP_MAX; ++k)
-                            if (k < kp) {
+                    for (int i = 0; i < 16; ++i) {
+                        double2 nxt[KP];
+                        rowoff = rot1_i32(rowoff);
+                        if (i < 15) {
+#pragma unroll
+                            for (int k = 0; k < KP; ++k) nxt[k] = tiles[k * LL + colbase + rowoff];
+                        }
+#pragma unroll
+                        for (int k = 0; k < KP; ++k) {
+                            sr[k] = fma(cur[k].x, ku, sr[k]);
+                            si[k] = fma(cur[k].y, ku, si[k]);
+                        }
+                        ku = rot1_f64(ku);
+                        if (i < 15) {
+#pragma unroll
+                            for (int k = 0; k < KP; ++k) cur[k] = nxt[k];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int off = colbase + arow * LS;
+                        if (arow < W && b < W) {
+#pragma unroll
+                            for (int k = 0; k < KP; ++k) {
                                 const double2 gval = tiles[k * LL + off];
                                 sr[k] = fma(gval.x, ku, sr[k]);
                                 si[k] = fma(gval.y, ku, si[k]);
                             }
+                        }
+                        ku = rot1_f64(ku);
+                        arow = rot1_i32(arow);
                     }
-                    ku = rot1_f64(ku);
-                    arow = rot1_i32(arow);
                 }
             }
             double tr = 0.0, ti = 0.0;
 #pragma unroll
-            for (int k = 0; k < KP_MAX; ++k) {
+            for (int k = 0; k < KP; ++k) {
                 tr = fma(sr[k], kw[k], tr);
                 ti = fma(si[k], kw[k], ti);
             }
