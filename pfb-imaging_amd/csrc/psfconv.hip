@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "psffft_api.hpp"
 #include "devcg.hpp"
 
 namespace pfbhip {
@@ -149,7 +150,8 @@ using namespace pfbhip;
 struct pfbhip_psfconv {
     int64_t nx, ny, nxp, nyp, nyo2;
     hipStream_t stream = nullptr;
-    RealFFT2D fft;
+    RealFFT2D fft;    // rocFFT 2-D r2c / c2r: the fallback for padded sizes the row-FFT pipeline does not take
+    PsfFFT own;       // three pruned row passes on the hand-written FFT (power-of-two padded sizes)
     DevBuf<double> xpad, d_x, d_out;
     DevBuf<double2> xhat;
     struct Slot {
@@ -181,6 +183,10 @@ struct pfbhip_psfconv {
             bm = beam[size_t(beam_slot)]->data.p;
         }
         Slot &ps = *psf[size_t(psf_slot)];
+        if (own.ok) {  // slot data is stored transposed, (nyo2, nxp)
+            own.apply(x_dev, bm, ps.data.p, ps.is_complex, mode, shift, scale, eta, accumulate, out_dev, stream);
+            return;
+        }
         dim3 blk(256);
         hipLaunchKernelGGL(k_psf_pad, dim3(uint32_t(ceil_div(nyp, 256)), uint32_t(nxp)), blk, 0, stream, x_dev, bm,
                            int(nx), int(ny), int(nxp), int(nyp), xpad.p);
@@ -212,9 +218,11 @@ int pfbhip_psfconv_create(int64_t nx, int64_t ny, int64_t nx_psf, int64_t ny_psf
         p->nyp = ny_psf;
         p->nyo2 = ny_psf / 2 + 1;
         PFB_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-        p->fft.create(nx_psf, ny_psf, p->stream);
-        p->xpad.alloc(size_t(nx_psf) * size_t(ny_psf));
-        p->xhat.alloc(size_t(nx_psf) * size_t(p->nyo2));
+        if (!p->own.init(nx, ny, nx_psf, ny_psf)) {
+            p->fft.create(nx_psf, ny_psf, p->stream);
+            p->xpad.alloc(size_t(nx_psf) * size_t(ny_psf));
+            p->xhat.alloc(size_t(nx_psf) * size_t(p->nyo2));
+        }
         *out = p.release();
     });
 }
@@ -231,8 +239,15 @@ int pfbhip_psfconv_set_psfhat(pfbhip_psfconv *p, int64_t slot, const double *psf
         auto &s = p->slot(p->psf, slot);
         size_t n = size_t(p->nxp) * size_t(p->nyo2) * (is_complex ? 2 : 1);
         s.data.ensure(n);
-        PFB_HIP(hipMemcpyAsync(s.data.p, psfhat_host, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
-        PFB_HIP(hipStreamSynchronize(p->stream));
+        if (p->own.ok) {  // keep (nyo2, nxp): the layout the per-frequency pass reads contiguously
+            DevBuf<double> tmp(n);
+            PFB_HIP(hipMemcpyAsync(tmp.p, psfhat_host, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+            p->own.transpose_psf(tmp.p, is_complex != 0, s.data.p, p->stream);
+            PFB_HIP(hipStreamSynchronize(p->stream));
+        } else {
+            PFB_HIP(hipMemcpyAsync(s.data.p, psfhat_host, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+            PFB_HIP(hipStreamSynchronize(p->stream));
+        }
         s.is_complex = is_complex != 0;
         s.bound = true;
     });

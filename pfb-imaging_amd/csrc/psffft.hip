@@ -1,0 +1,269 @@
+// psffft.hip -- PSF convolution (psf_convolve_* / hessian_psf_*, src/pfb_imaging/operators/psf.py:14-104,
+// operators/hessian.py:92-140, 326-348) on the hand-written row FFT: see psffft_api.hpp for the pipeline.
+// Compiled with FMA contraction ON (no bit-exact index arithmetic lives in this file).
+#pragma clang fp contract(fast)
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "common.hpp"
+#include "psffft_api.hpp"
+#include "rowfft.hpp"
+
+namespace pfbhip {
+
+#define PSF_FOR_SHAPES(X) X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14)
+
+// out (cols, rows) = in (rows, cols)^T, 32 x 32 tiles through LDS
+template <class T>
+__global__ void __launch_bounds__(256) k_transpose_any(const T *__restrict__ in, int rows, int cols, size_t ld_in,
+                                                        T *__restrict__ out, size_t ld_out)
+{
+    __shared__ T tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + int(threadIdx.x);
+        if (r < rows && c < cols) tile[j][threadIdx.x] = in[size_t(r) * ld_in + size_t(c)];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + int(threadIdx.x);
+        if (r < rows && c < cols) out[size_t(c) * ld_out + size_t(r)] = tile[threadIdx.x][j];
+    }
+}
+
+template <class T>
+static void transpose_any(const T *in, int64_t rows, int64_t cols, size_t ld_in, T *out, size_t ld_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_transpose_any<T>, dim3(uint32_t(ceil_div(cols, 32)), uint32_t(ceil_div(rows, 32))), dim3(32, 8), 0, st,
+                       in, int(rows), int(cols), ld_in, out, ld_out);
+    PFB_HIP(hipGetLastError());
+}
+
+// ---- pass 1: rows of beam * x, zero-padded to nyp, forward along y, half spectrum kept --------------
+struct PsfPadLoad {
+    const double *xrow, *brow;
+    int ny;
+    __device__ __forceinline__ double2 operator()(int u, int) const
+    {
+        if (u >= ny) return make_double2(0.0, 0.0);
+        double v = xrow[u];
+        if (brow != nullptr) v *= brow[u];
+        return make_double2(v, 0.0);
+    }
+};
+
+template <class S>
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_rows_fwd(const double2 *tw, const double *x, const double *beam,
+                                                                          int ny, double2 *t1, size_t ld1)
+{
+    extern __shared__ double rf_lds[];
+    const size_t row = blockIdx.x;
+    PsfPadLoad ld{x + row * size_t(ny), beam != nullptr ? beam + row * size_t(ny) : nullptr, ny};
+    double re[S::E], im[S::E];
+    int t;
+    rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
+    double2 *orow = t1 + row * ld1;
+#pragma unroll
+    for (int e = 0; e < S::E; ++e) {
+        const int k = S::out_pos(t, e);
+        if (k <= S::N / 2) orow[k] = make_double2(re[e], im[e]);
+    }
+}
+
+// ---- pass 2: per y-frequency: forward along x, times f(psfhat), inverse along x ----------------------
+struct PsfColLoad {
+    const double2 *row;
+    int nx;
+    __device__ __forceinline__ double2 operator()(int p, int) const
+    {
+        return p < nx ? row[p] : make_double2(0.0, 0.0);
+    }
+};
+
+// mode 0: psf, 1: psf + shift, 2: 1 / (psf + shift); norm = 1 / (nxp nyp) folded in
+template <class S>
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_cols(const double2 *tw, double2 *t2, int nx, const double *psfT,
+                                                                      int is_complex, int mode, double shift, double norm)
+{
+    extern __shared__ double rf_lds[];
+    const size_t k = blockIdx.x;
+    double2 *row = t2 + k * size_t(nx);
+    PsfColLoad ld{row, nx};
+    double re[S::E], im[S::E];
+    int t;
+    rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
+    // The forward transform leaves position t + rf_last_slot(e) T in slot e: a permutation of the
+    // thread's own natural set {t + e T}.  The inverse transform therefore starts from registers
+    // (power-of-two lengths: no leading radix-3/5 pass, whose inputs would belong to other threads).
+    double re2[S::E], im2[S::E];
+#pragma unroll
+    for (int e = 0; e < S::E; ++e) {
+        const int kx = S::out_pos(t, e);
+        double pr, pi = 0.0;
+        if (is_complex) {
+            const double2 pv = reinterpret_cast<const double2 *>(psfT)[k * size_t(S::N) + size_t(kx)];
+            pr = pv.x;
+            pi = pv.y;
+        } else {
+            pr = psfT[k * size_t(S::N) + size_t(kx)];
+        }
+        if (mode != 0) pr += shift;
+        double yr, yi;
+        if (mode == 2) {  // v / (pr + i pi)
+            const double d = norm / (pr * pr + pi * pi);
+            yr = (re[e] * pr + im[e] * pi) * d;
+            yi = (im[e] * pr - re[e] * pi) * d;
+        } else {
+            yr = (re[e] * pr - im[e] * pi) * norm;
+            yi = (re[e] * pi + im[e] * pr) * norm;
+        }
+        const int s = rf_last_slot(S::RLAST, S::E, e);
+        re2[s] = yi;  // inverse transform = forward transform of the swapped components
+        im2[s] = yr;
+    }
+    const double2 w0[S::E / rf_radix(S::K, 0)] = {};
+    rf_passes<S, 0, 1>(re2, im2, t, tw, rf_lds, w0);
+#pragma unroll
+    for (int e = 0; e < S::E; ++e) {
+        const int p = S::out_pos(t, e);
+        if (p < nx) row[p] = make_double2(im2[e], re2[e]);
+    }
+}
+
+// ---- pass 3: rows: Hermitian-extended inverse along y, real part, crop, beam, scale, eta --------------
+struct PsfHermLoad {
+    const double2 *row;
+    int N;
+    __device__ __forceinline__ double2 operator()(int k, int) const
+    {
+        if (k <= N / 2) return row[k];
+        const double2 v = row[N - k];
+        return make_double2(v.x, -v.y);
+    }
+};
+
+template <class S>
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_rows_inv(const double2 *tw, const double2 *t1, size_t ld1,
+                                                                          const double *beam, const double *x, int ny,
+                                                                          double scale, double eta, int accumulate, double *out)
+{
+    extern __shared__ double rf_lds[];
+    const size_t row = blockIdx.x;
+    PsfHermLoad ld{t1 + row * ld1, S::N};
+    double re[S::E], im[S::E];
+    int t;
+    rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
+#pragma unroll
+    for (int e = 0; e < S::E; ++e) {
+        const int u = S::out_pos(t, e);
+        if (u < ny) {
+            const size_t o = row * size_t(ny) + size_t(u);
+            double v = im[e];  // inverse transform: value = (im, re); the imaginary part is rounding noise
+            if (beam != nullptr) v *= beam[o];
+            v *= scale;
+            if (eta != 0.0) v += eta * x[o];
+            out[o] = accumulate ? out[o] + v : v;
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+
+template <class Kern>
+static void psf_allow_lds(Kern kern, bool *done)
+{
+    if (*done) return;
+    PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    *done = true;
+}
+
+bool PsfFFT::init(int64_t nx_, int64_t ny_, int64_t nxp_, int64_t nyp_)
+{
+    ok = false;
+    const char *env = std::getenv("PFBHIP_PSF_ROWFFT");
+    if (env != nullptr && env[0] == '0') return false;
+    RowFFTPlan a, b;
+    if (!rowfft_make_plan(nxp_, &a) || !rowfft_make_plan(nyp_, &b) || a.lead != 1 || b.lead != 1) return false;
+    if (nx_ > nxp_ || ny_ > nyp_) return false;
+    nx = nx_;
+    ny = ny_;
+    nxp = nxp_;
+    nyp = nyp_;
+    nyo2 = nyp / 2 + 1;
+    ld1 = size_t(ceil_div(nyo2, 32) * 32);
+    if (!fy.init(nyp) || !fx.init(nxp)) return false;
+    t1.alloc(size_t(nx) * ld1);
+    t2.alloc(size_t(nyo2) * size_t(nx));
+    ok = true;
+    return true;
+}
+
+void PsfFFT::transpose_psf(const double *src_dev, bool is_complex, double *dst_dev, hipStream_t st) const
+{
+    if (is_complex)
+        transpose_any(reinterpret_cast<const double2 *>(src_dev), nxp, nyo2, size_t(nyo2), reinterpret_cast<double2 *>(dst_dev),
+                      size_t(nxp), st);
+    else
+        transpose_any(src_dev, nxp, nyo2, size_t(nyo2), dst_dev, size_t(nxp), st);
+}
+
+template <class S>
+static void launch_rows_fwd(const PsfFFT &p, const double *x, const double *beam, hipStream_t st)
+{
+    static bool attr = false;
+    psf_allow_lds(&k_psf_rows_fwd<S>, &attr);
+    hipLaunchKernelGGL(k_psf_rows_fwd<S>, dim3(uint32_t(p.nx)), dim3(S::T), size_t(S::LDS_BYTES), st, p.fy.pl.twiddle, x, beam,
+                       int(p.ny), p.t1.p, p.ld1);
+}
+template <class S>
+static void launch_cols(const PsfFFT &p, const double *psfT, bool is_complex, int mode, double shift, hipStream_t st)
+{
+    static bool attr = false;
+    psf_allow_lds(&k_psf_cols<S>, &attr);
+    hipLaunchKernelGGL(k_psf_cols<S>, dim3(uint32_t(p.nyo2)), dim3(S::T), size_t(S::LDS_BYTES), st, p.fx.pl.twiddle, p.t2.p,
+                       int(p.nx), psfT, is_complex ? 1 : 0, mode, shift, 1.0 / (double(p.nxp) * double(p.nyp)));
+}
+template <class S>
+static void launch_rows_inv(const PsfFFT &p, const double *beam, const double *x, double scale, double eta, int accumulate,
+                            double *out, hipStream_t st)
+{
+    static bool attr = false;
+    psf_allow_lds(&k_psf_rows_inv<S>, &attr);
+    hipLaunchKernelGGL(k_psf_rows_inv<S>, dim3(uint32_t(p.nx)), dim3(S::T), size_t(S::LDS_BYTES), st, p.fy.pl.twiddle, p.t1.p,
+                       p.ld1, beam, x, int(p.ny), scale, eta, accumulate, out);
+}
+
+void PsfFFT::apply(const double *x_dev, const double *beam_dev, const double *psfT_dev, bool is_complex, int mode, double shift,
+                   double scale, double eta, int accumulate, double *out_dev, hipStream_t st)
+{
+    PFB_REQUIRE(ok, "PSF row-FFT plan is not initialised");
+    switch (nyp) {
+#define RF_X(L, K) \
+    case (L << K): launch_rows_fwd<RfShape<L, K>>(*this, x_dev, beam_dev, st); break;
+        PSF_FOR_SHAPES(RF_X)
+#undef RF_X
+        default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nyp);
+    }
+    PFB_HIP(hipGetLastError());
+    transpose_any(t1.p, nx, nyo2, ld1, t2.p, size_t(nx), st);
+    switch (nxp) {
+#define RF_X(L, K) \
+    case (L << K): launch_cols<RfShape<L, K>>(*this, psfT_dev, is_complex, mode, shift, st); break;
+        PSF_FOR_SHAPES(RF_X)
+#undef RF_X
+        default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nxp);
+    }
+    PFB_HIP(hipGetLastError());
+    transpose_any(t2.p, nyo2, nx, size_t(nx), t1.p, ld1, st);
+    switch (nyp) {
+#define RF_X(L, K) \
+    case (L << K): launch_rows_inv<RfShape<L, K>>(*this, beam_dev, x_dev, scale, eta, accumulate, out_dev, st); break;
+        PSF_FOR_SHAPES(RF_X)
+#undef RF_X
+        default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nyp);
+    }
+    PFB_HIP(hipGetLastError());
+}
+
+}  // namespace pfbhip

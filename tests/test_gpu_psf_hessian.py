@@ -270,3 +270,51 @@ def test_hessian_equals_psf_convolution(center_offset):
     scale = np.abs(res2).max()
     diff = (res2 - res1) / scale
     assert np.allclose(1 + diff, 1)
+
+
+@pytest.mark.parametrize("is_complex", [False, True])
+def test_psfconv_rowfft_pipeline(is_complex, monkeypatch):
+    """Power-of-two padded sizes take the three-pass row-FFT pipeline (csrc/psffft.hip); every mode, beam,
+    eta and accumulate against numpy, and against the rocFFT fallback (PFBHIP_PSF_ROWFFT=0)."""
+    from pfb_imaging_amd.psfconv import PsfConv
+
+    rng = np.random.default_rng(11)
+    nx, ny, nxp, nyp = 600, 520, 2048, 1024
+    psf = rng.standard_normal((nxp, nyp))
+    psfhat = np.fft.rfft2(np.fft.ifftshift(psf))
+    ph = psfhat if is_complex else 1.0 + np.abs(psfhat) / np.abs(psfhat).max()
+    x = rng.standard_normal((nx, ny))
+    beam = 0.5 + rng.random((nx, ny))
+    prev = rng.standard_normal((nx, ny))
+
+    def ref(mode, shift, bm, scale, eta, acc):
+        xp = np.zeros((nxp, nyp))
+        xp[:nx, :ny] = x * (bm if bm is not None else 1.0)
+        xh = np.fft.rfft2(xp)
+        f = ph if mode == 0 else (ph + shift if mode == 1 else 1.0 / (ph + shift))
+        r = np.fft.irfft2(xh * f, s=(nxp, nyp))[:nx, :ny] * (bm if bm is not None else 1.0) * scale + eta * x
+        return r + prev if acc else r
+
+    cases = [(0, 0.0, None, 1.0, 0.0, False), (0, 0.0, beam, 0.7, 0.3, False), (1, 2.5, beam, 1.0, 0.0, True),
+             (2, 2.5, None, 1.3, 0.1, False)]
+    results = {}
+    for env in (None, "0"):
+        if env is None:
+            monkeypatch.delenv("PFBHIP_PSF_ROWFFT", raising=False)
+        else:
+            monkeypatch.setenv("PFBHIP_PSF_ROWFFT", env)
+        pc = PsfConv(nx, ny, nxp, nyp)
+        pc.set_psfhat(0, ph)
+        pc.set_beam(0, beam)
+        for i, (mode, shift, bm, scale, eta, acc) in enumerate(cases):
+            if mode == 2 and is_complex:
+                shift = 3.0 * np.abs(psfhat).max()  # keep the complex denominator away from zero
+            out = prev.copy() if acc else None
+            got = pc.apply(x, 0, beam_slot=0 if bm is not None else -1, mode=mode, shift=shift, scale=scale, eta=eta,
+                           out=out, accumulate=acc)
+            want = ref(mode, shift, bm, scale, eta, acc)
+            assert rel(got, want) < 1e-12, (env, i)
+            results[(env, i)] = got
+        pc.close()
+    for i in range(len(cases)):
+        assert rel(results[(None, i)], results[("0", i)]) < 1e-12
