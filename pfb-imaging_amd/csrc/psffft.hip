@@ -13,6 +13,10 @@
 namespace pfbhip {
 
 #define PSF_FOR_SHAPES(X) X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14)
+// (32 complex per thread at 16384 points -- 512 threads, 256 VGPRs -- was tried against the 1024-thread /
+// 128-VGPR layout and its 35-120 spilled registers in these fused kernels: it spills more.)
+template <int L, int K>
+using PsfShape = RfShape<L, K>;
 
 // out (cols, rows) = in (rows, cols)^T, 32 x 32 tiles through LDS
 template <class T>
@@ -41,33 +45,60 @@ static void transpose_any(const T *in, int64_t rows, int64_t cols, size_t ld_in,
 }
 
 // ---- pass 1: rows of beam * x, zero-padded to nyp, forward along y, half spectrum kept --------------
-struct PsfPadLoad {
-    const double *xrow, *brow;
+// Two real rows share one complex transform: z = a + i b, A[k] = (Z[k] + conj Z[N-k]) / 2,
+// B[k] = (Z[k] - conj Z[N-k]) / 2i.  The partner Z[N-k] lives in another thread: one more LDS exchange
+// (component by component) after the last pass -- 10 % of a transform to save a whole one.
+struct PsfPadLoad2 {
+    const double *xa, *xb, *ba, *bb;  // rows 2r and 2r+1 (xb == NULL: no second row)
     int ny;
     __device__ __forceinline__ double2 operator()(int u, int) const
     {
         if (u >= ny) return make_double2(0.0, 0.0);
-        double v = xrow[u];
-        if (brow != nullptr) v *= brow[u];
-        return make_double2(v, 0.0);
+        double va = xa[u], vb = xb != nullptr ? xb[u] : 0.0;
+        if (ba != nullptr) {
+            va *= ba[u];
+            if (xb != nullptr) vb *= bb[u];
+        }
+        return make_double2(va, vb);
     }
 };
 
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_rows_fwd(const double2 *tw, const double *x, const double *beam,
-                                                                          int ny, double2 *t1, size_t ld1)
+                                                                          int nx, int ny, double2 *t1, size_t ld1)
 {
     extern __shared__ double rf_lds[];
-    const size_t row = blockIdx.x;
-    PsfPadLoad ld{x + row * size_t(ny), beam != nullptr ? beam + row * size_t(ny) : nullptr, ny};
+    const size_t r0 = size_t(blockIdx.x) * 2;
+    const bool two = r0 + 1 < size_t(nx);
+    PsfPadLoad2 ld{x + r0 * size_t(ny), two ? x + (r0 + 1) * size_t(ny) : nullptr,
+                   beam != nullptr ? beam + r0 * size_t(ny) : nullptr,
+                   (beam != nullptr && two) ? beam + (r0 + 1) * size_t(ny) : nullptr, ny};
     double re[S::E], im[S::E];
     int t;
     rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
-    double2 *orow = t1 + row * ld1;
+    rf_opaque(t);
+    // partner values Z[(N - k) mod N], one component at a time through the (now free) transpose buffer
+    double pre[S::E], pim[S::E];
+    rf_barrier();
+#pragma unroll
+    for (int e = 0; e < S::E; ++e) rf_lds[rf_swz(S::out_pos(t, e))] = re[e];
+    rf_barrier();
+#pragma unroll
+    for (int e = 0; e < S::E; ++e) pre[e] = rf_lds[rf_swz((S::N - S::out_pos(t, e)) & (S::N - 1))];
+    rf_barrier();
+#pragma unroll
+    for (int e = 0; e < S::E; ++e) rf_lds[rf_swz(S::out_pos(t, e))] = im[e];
+    rf_barrier();
+#pragma unroll
+    for (int e = 0; e < S::E; ++e) pim[e] = rf_lds[rf_swz((S::N - S::out_pos(t, e)) & (S::N - 1))];
+    double2 *rowa = t1 + r0 * ld1, *rowb = rowa + ld1;
 #pragma unroll
     for (int e = 0; e < S::E; ++e) {
         const int k = S::out_pos(t, e);
-        if (k <= S::N / 2) orow[k] = make_double2(re[e], im[e]);
+        if (k <= S::N / 2) {
+            rowa[k] = make_double2(0.5 * (re[e] + pre[e]), 0.5 * (im[e] - pim[e]));
+            if (two) rowb[k] = make_double2(0.5 * (im[e] + pim[e]), 0.5 * (pre[e] - re[e]));
+        }
     }
 }
 
@@ -97,73 +128,100 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_cols(const doub
     // thread's own natural set {t + e T}.  The inverse transform therefore starts from registers
     // (power-of-two lengths: no leading radix-3/5 pass, whose inputs would belong to other threads).
     double re2[S::E], im2[S::E];
+    const double *prow = psfT + k * size_t(S::N) * (is_complex ? 2 : 1);
+    __builtin_amdgcn_sched_barrier(0);  // the psfhat loads belong between the transforms, not inside the first
 #pragma unroll
-    for (int e = 0; e < S::E; ++e) {
-        const int kx = S::out_pos(t, e);
-        double pr, pi = 0.0;
-        if (is_complex) {
-            const double2 pv = reinterpret_cast<const double2 *>(psfT)[k * size_t(S::N) + size_t(kx)];
-            pr = pv.x;
-            pi = pv.y;
-        } else {
-            pr = psfT[k * size_t(S::N) + size_t(kx)];
+    for (int e0 = 0; e0 < S::E; e0 += 4) {
+        double pr[4], pi[4];
+#pragma unroll
+        for (int e = e0; e < e0 + 4; ++e) {
+            const int kx = S::out_pos(t, e);
+            if (is_complex) {
+                const double2 pv = reinterpret_cast<const double2 *>(prow)[kx];
+                pr[e - e0] = pv.x;
+                pi[e - e0] = pv.y;
+            } else {
+                pr[e - e0] = prow[kx];
+                pi[e - e0] = 0.0;
+            }
         }
-        if (mode != 0) pr += shift;
-        double yr, yi;
-        if (mode == 2) {  // v / (pr + i pi)
-            const double d = norm / (pr * pr + pi * pi);
-            yr = (re[e] * pr + im[e] * pi) * d;
-            yi = (im[e] * pr - re[e] * pi) * d;
-        } else {
-            yr = (re[e] * pr - im[e] * pi) * norm;
-            yi = (re[e] * pi + im[e] * pr) * norm;
+#pragma unroll
+        for (int e = e0; e < e0 + 4; ++e) {
+            double p_r = pr[e - e0];
+            const double p_i = pi[e - e0];
+            if (mode != 0) p_r += shift;
+            double yr, yi;
+            if (mode == 2) {  // v / (pr + i pi)
+                const double d = norm / (p_r * p_r + p_i * p_i);
+                yr = (re[e] * p_r + im[e] * p_i) * d;
+                yi = (im[e] * p_r - re[e] * p_i) * d;
+            } else {
+                yr = (re[e] * p_r - im[e] * p_i) * norm;
+                yi = (re[e] * p_i + im[e] * p_r) * norm;
+            }
+            const int s = rf_last_slot(S::RLAST, S::E, e);
+            re2[s] = yi;  // inverse transform = forward transform of the swapped components
+            im2[s] = yr;
         }
-        const int s = rf_last_slot(S::RLAST, S::E, e);
-        re2[s] = yi;  // inverse transform = forward transform of the swapped components
-        im2[s] = yr;
+        __builtin_amdgcn_sched_barrier(0);
     }
     const double2 w0[S::E / rf_radix(S::K, 0)] = {};
-    rf_passes<S, 0, 1>(re2, im2, t, tw, rf_lds, w0);
+    // a second opaque copy of the thread index: otherwise the LDS / twiddle addresses of the second
+    // transform are common subexpressions of the first and stay live through it (130 spilled VGPRs)
+    int tb = t;
+    rf_opaque(tb);
+    rf_passes<S, 0, 1>(re2, im2, tb, tw, rf_lds, w0);
 #pragma unroll
     for (int e = 0; e < S::E; ++e) {
-        const int p = S::out_pos(t, e);
+        const int p = S::out_pos(tb, e);
         if (p < nx) row[p] = make_double2(im2[e], re2[e]);
     }
 }
 
 // ---- pass 3: rows: Hermitian-extended inverse along y, real part, crop, beam, scale, eta --------------
-struct PsfHermLoad {
-    const double2 *row;
+// Two output rows per transform: Z = A + i B (both Hermitian-extended), z = a + i b.
+struct PsfHermLoad2 {
+    const double2 *rowa, *rowb;  // rowb == NULL: single row
     int N;
     __device__ __forceinline__ double2 operator()(int k, int) const
     {
-        if (k <= N / 2) return row[k];
-        const double2 v = row[N - k];
-        return make_double2(v.x, -v.y);
+        const bool lo = k <= N / 2;
+        const int kk = lo ? k : N - k;
+        const double2 a = rowa[kk];
+        const double2 b = rowb != nullptr ? rowb[kk] : make_double2(0.0, 0.0);
+        // lo: a + i b ; hi: conj(a) + i conj(b)
+        return lo ? make_double2(a.x - b.y, a.y + b.x) : make_double2(a.x + b.y, b.x - a.y);
     }
 };
 
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_rows_inv(const double2 *tw, const double2 *t1, size_t ld1,
-                                                                          const double *beam, const double *x, int ny,
+                                                                          const double *beam, const double *x, int nx, int ny,
                                                                           double scale, double eta, int accumulate, double *out)
 {
     extern __shared__ double rf_lds[];
-    const size_t row = blockIdx.x;
-    PsfHermLoad ld{t1 + row * ld1, S::N};
+    const size_t r0 = size_t(blockIdx.x) * 2;
+    const bool two = r0 + 1 < size_t(nx);
+    PsfHermLoad2 ld{t1 + r0 * ld1, two ? t1 + (r0 + 1) * ld1 : nullptr, S::N};
     double re[S::E], im[S::E];
     int t;
     rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
+    rf_opaque(t);
 #pragma unroll
     for (int e = 0; e < S::E; ++e) {
         const int u = S::out_pos(t, e);
         if (u < ny) {
-            const size_t o = row * size_t(ny) + size_t(u);
-            double v = im[e];  // inverse transform: value = (im, re); the imaginary part is rounding noise
-            if (beam != nullptr) v *= beam[o];
-            v *= scale;
-            if (eta != 0.0) v += eta * x[o];
-            out[o] = accumulate ? out[o] + v : v;
+            // inverse transform: value = (im, re) = (row 2r, row 2r+1)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && !two) break;
+                const size_t o = (r0 + size_t(h)) * size_t(ny) + size_t(u);
+                double v = h == 0 ? im[e] : re[e];
+                if (beam != nullptr) v *= beam[o];
+                v *= scale;
+                if (eta != 0.0) v += eta * x[o];
+                out[o] = accumulate ? out[o] + v : v;
+            }
         }
     }
 }
@@ -213,8 +271,8 @@ static void launch_rows_fwd(const PsfFFT &p, const double *x, const double *beam
 {
     static bool attr = false;
     psf_allow_lds(&k_psf_rows_fwd<S>, &attr);
-    hipLaunchKernelGGL(k_psf_rows_fwd<S>, dim3(uint32_t(p.nx)), dim3(S::T), size_t(S::LDS_BYTES), st, p.fy.pl.twiddle, x, beam,
-                       int(p.ny), p.t1.p, p.ld1);
+    hipLaunchKernelGGL(k_psf_rows_fwd<S>, dim3(uint32_t((p.nx + 1) / 2)), dim3(S::T), size_t(S::LDS_BYTES), st, p.fy.pl.twiddle,
+                       x, beam, int(p.nx), int(p.ny), p.t1.p, p.ld1);
 }
 template <class S>
 static void launch_cols(const PsfFFT &p, const double *psfT, bool is_complex, int mode, double shift, hipStream_t st)
@@ -230,8 +288,8 @@ static void launch_rows_inv(const PsfFFT &p, const double *beam, const double *x
 {
     static bool attr = false;
     psf_allow_lds(&k_psf_rows_inv<S>, &attr);
-    hipLaunchKernelGGL(k_psf_rows_inv<S>, dim3(uint32_t(p.nx)), dim3(S::T), size_t(S::LDS_BYTES), st, p.fy.pl.twiddle, p.t1.p,
-                       p.ld1, beam, x, int(p.ny), scale, eta, accumulate, out);
+    hipLaunchKernelGGL(k_psf_rows_inv<S>, dim3(uint32_t((p.nx + 1) / 2)), dim3(S::T), size_t(S::LDS_BYTES), st, p.fy.pl.twiddle,
+                       p.t1.p, p.ld1, beam, x, int(p.nx), int(p.ny), scale, eta, accumulate, out);
 }
 
 void PsfFFT::apply(const double *x_dev, const double *beam_dev, const double *psfT_dev, bool is_complex, int mode, double shift,
@@ -240,7 +298,7 @@ void PsfFFT::apply(const double *x_dev, const double *beam_dev, const double *ps
     PFB_REQUIRE(ok, "PSF row-FFT plan is not initialised");
     switch (nyp) {
 #define RF_X(L, K) \
-    case (L << K): launch_rows_fwd<RfShape<L, K>>(*this, x_dev, beam_dev, st); break;
+    case (L << K): launch_rows_fwd<PsfShape<L, K>>(*this, x_dev, beam_dev, st); break;
         PSF_FOR_SHAPES(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nyp);
@@ -249,7 +307,7 @@ void PsfFFT::apply(const double *x_dev, const double *beam_dev, const double *ps
     transpose_any(t1.p, nx, nyo2, ld1, t2.p, size_t(nx), st);
     switch (nxp) {
 #define RF_X(L, K) \
-    case (L << K): launch_cols<RfShape<L, K>>(*this, psfT_dev, is_complex, mode, shift, st); break;
+    case (L << K): launch_cols<PsfShape<L, K>>(*this, psfT_dev, is_complex, mode, shift, st); break;
         PSF_FOR_SHAPES(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nxp);
@@ -258,7 +316,7 @@ void PsfFFT::apply(const double *x_dev, const double *beam_dev, const double *ps
     transpose_any(t2.p, nyo2, nx, size_t(nx), t1.p, ld1, st);
     switch (nyp) {
 #define RF_X(L, K) \
-    case (L << K): launch_rows_inv<RfShape<L, K>>(*this, beam_dev, x_dev, scale, eta, accumulate, out_dev, st); break;
+    case (L << K): launch_rows_inv<PsfShape<L, K>>(*this, beam_dev, x_dev, scale, eta, accumulate, out_dev, st); break;
         PSF_FOR_SHAPES(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nyp);

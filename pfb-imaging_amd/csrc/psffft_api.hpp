@@ -1,12 +1,14 @@
 // psffft_api.hpp -- PSF convolution on the hand-written row FFT (defined in psffft.hip).
 //
 // out = [out +] beam * crop( c2r( f(psfhat) * r2c( pad(beam * x) ) ) ) * scale + eta * x   as three row passes:
-//   1. the nx non-zero rows of the padded image: forward FFT along y, half spectrum kept        -> T1 (nx, nyo2)
+//   1. the nx non-zero rows of the padded image, two real rows per complex transform: forward FFT
+//      along y, un-mixed through LDS, half spectrum kept                                        -> T1 (nx, nyo2)
 //      transpose                                                                                -> T2 (nyo2, nx)
 //   2. per y-frequency: zero-padded forward FFT along x, times f(psfhat) / N, inverse FFT along x in the
 //      same registers, the first nx outputs kept                                                -> T2 (in place)
 //      transpose back                                                                           -> T1
-//   3. the nx output rows: Hermitian-extended inverse FFT along y, real part, crop, beam, scale, eta
+//   3. the nx output rows, two per transform (Z = A + i B): Hermitian-extended inverse FFT along y, real and
+//      imaginary parts, crop, beam, scale, eta
 // Nothing outside the nx x nyo2 corner is ever stored: ~6 GB of traffic at 8192^2 / 16384^2 where the
 // padded r2c / c2r pipeline moves ~24 GB.  Needs power-of-two padded sizes in 1024..16384.
 #pragma once

@@ -189,6 +189,7 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
         double re[S::E], im[S::E];
         int t;
         rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
+        rf_opaque(t);
         const double wk = planes.w[k];
         const bool last = k == planes.kp - 1;
         // what must be added to this plane's value: the LDS running sum (thread-private cells, no barrier)
@@ -275,6 +276,7 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
         double re[S::E], im[S::E];
         int t;
         rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
+        rf_opaque(t);
         double2 *brow = B + size_t(k) * bstride + size_t(y) * g.nu;
 #pragma unroll
         for (int e = 0; e < S::E; ++e)

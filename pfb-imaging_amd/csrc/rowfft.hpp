@@ -35,7 +35,10 @@ namespace pfbhip {
 #ifndef RF_E32_MAXN
 #define RF_E32_MAXN 0
 #endif
-constexpr int rf_elems(int N) { return (N >= 4096 && N <= RF_E32_MAXN) ? 32 : 16; }
+#ifndef RF_E32_MINN
+#define RF_E32_MINN 4096
+#endif
+constexpr int rf_elems(int N) { return (N >= RF_E32_MINN && N <= RF_E32_MAXN) ? 32 : 16; }
 
 struct RowFFTPlan {
     int N = 0, T = 0, lead = 0, K = 0;
@@ -379,10 +382,10 @@ __device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], i
 }
 
 // Compile-time description of one supported row length.
-template <int LEAD_, int K_, bool ALLOW_DUAL = true>
+template <int LEAD_, int K_, bool ALLOW_DUAL = true, int E_ = 0>
 struct RfShape {
     static constexpr int LEAD = LEAD_, K = K_;
-    static constexpr int N = LEAD_ << K_, E = rf_elems(N), T = N / E;
+    static constexpr int N = LEAD_ << K_, E = E_ > 0 ? E_ : rf_elems(N), T = N / E;
     static constexpr int NP = rf_npass(K_);
     static constexpr int RLAST = rf_radix(K_, NP - 1);
     // E = 32 shapes run two workgroups per CU and therefore transpose one component at a time
@@ -417,6 +420,11 @@ __device__ __forceinline__ void rf_passes(double (&re)[S::E], double (&im)[S::E]
         rf_passes<S, P + 1, NS * R>(re, im, t, tw, lds, w2);
     }
 }
+
+// Makes the thread index opaque to the optimiser again.  Callers put it between a transform and their
+// epilogue: otherwise the epilogue's addresses (functions of t) are computed before the transform and
+// stay live through it -- tens of VGPRs the passes need.
+__device__ __forceinline__ void rf_opaque(int &t) { asm volatile("" : "+v"(t)); }
 
 // load -> passes; on return slot e holds the transform at position S::out_pos(t, e) as
 // (re[e], im[e]) for the forward transform and as (im[e], re[e]) for the (unnormalised) inverse.
@@ -473,6 +481,7 @@ __device__ __forceinline__ void rf_row(const double2 *__restrict__ tw, Load &ld,
     double re[S::E], im[S::E];
     int t;
     rf_row_compute<S>(tw, ld, inverse, lds, t, re, im);
+    rf_opaque(t);
 #pragma unroll
     for (int e = 0; e < S::E; ++e)
         st(S::out_pos(t, e), inverse ? make_double2(im[e], re[e]) : make_double2(re[e], im[e]));
