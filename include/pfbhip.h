@@ -245,6 +245,40 @@ int pfbhip_box_sum_counts(const double *counts_host, int64_t ncorr, int64_t nx, 
  * raised to that value, in place; the median is returned through median_out (may be NULL). */
 int pfbhip_filter_extreme_counts(double *counts_host, int64_t n, double level, double *median_out);
 
+/* ---- wavelet dictionary Psi and the l21 / positivity proxes ---------------- */
+/*
+ * One band's dictionary: replaces PsiBandNocopyt (src/pfb_imaging/operators/psi.py:415-535; multi-level 2-D
+ * DWT of wavelets/wavelets.py:216-343 on the 1-D kernels of wavelets/convolutions.py:5-327, zero-padding
+ * mode, packed x-first layout of psi.py:23-142).  bases[i]: 0 = "self" (identity), N = "dbN" (1..8).
+ * x is (nx, ny), alpha is (nbasis, nxmax, nymax) with (nxmax, nymax) from pfbhip_psi_shape; nx, ny even.
+ * dot = image -> coefficients (every element of alpha is written), hdot = coefficients -> image, summed
+ * over the bases.  transposed != 0 on the host entries: alpha is (nbasis, nymax, nxmax), the layout of the
+ * reference's older Psi (psi.py:218-345).
+ */
+typedef struct pfbhip_psi pfbhip_psi;
+int pfbhip_psi_create(int64_t nx, int64_t ny, int32_t nbasis, const int32_t *bases, int32_t nlevel, pfbhip_psi **out);
+int pfbhip_psi_destroy(pfbhip_psi *p);
+int pfbhip_psi_shape(const pfbhip_psi *p, int64_t *nxmax, int64_t *nymax);
+int pfbhip_psi_dot(pfbhip_psi *p, const double *x_host, double *alpha_host, int transposed);
+int pfbhip_psi_hdot(pfbhip_psi *p, const double *alpha_host, double *x_host, int transposed);
+int pfbhip_psi_dot_dev(pfbhip_psi *p, const double *x_dev, double *alpha_dev);
+int pfbhip_psi_hdot_dev(pfbhip_psi *p, const double *alpha_dev, double *x_dev);
+
+/* dual_update_numba_fast (src/pfb_imaging/prox/prox_21m.py:105-135): v <- vtilde min(1, lam w / |sum_band vtilde|),
+ * vtilde = vp + sigma v, arrays (nband, n), weight (n), in place on v.  With bands spread over ranks the
+ * update is two device phases around one all-reduce of the band sum (pfbhip_comm_allreduce_sum):
+ * vtilde_sum (v <- vtilde, sum over the LOCAL bands) and scale (given the sum over ALL bands). */
+int pfbhip_dual_update(const double *vp_host, double *v_host, int64_t nband, int64_t n, double lam, double sigma,
+                       const double *weight_host);
+int pfbhip_l21_vtilde_sum_dev(const double *vp_dev, double *v_dev, int64_t nband, int64_t n, double sigma, double *sum_dev);
+int pfbhip_l21_scale_dev(double *v_dev, int64_t nband, int64_t n, double lam, const double *weight_dev, const double *sum_dev);
+/* prox_21m (prox_21m.py:5-26): out = v max(|s| - sigma w, 0) / |s|, s = band sum; weight may be NULL (= 1). */
+int pfbhip_prox_21m(const double *v_host, int64_t nband, int64_t n, double sigma, const double *weight_host, double *out_host);
+/* positivity (prox/positivity.py:12-33): mode 1 clamps negatives, mode 2 zeroes a pixel in all bands where any
+ * band is <= 0; x is (nband, n), in place. */
+int pfbhip_positivity(double *x_host, int64_t nband, int64_t n, int mode);
+int pfbhip_positivity_dev(double *x_dev, int64_t nband, int64_t n, int mode);
+
 /* ---- band reduce over xGMI (RCCL) ------------------------------------ */
 /*
  * Replaces the driver-side band sums of the reference

@@ -1,0 +1,102 @@
+"""GPU parity of the wavelet dictionary Psi and the l21 / positivity proxes against the CPU oracle
+(oracle/psi.py, a restatement of the reference's numba code; see its header: parity unpinned by fixtures)."""
+
+import numpy as np
+import pytest
+
+from oracle import psi as opsi
+
+pytestmark = pytest.mark.gpu
+
+rel = lambda a, b: np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+@pytest.mark.parametrize("bases,nlevel,shape", [
+    (("self", "db1", "db2", "db3"), 3, (128, 96)),     # the reference's default dictionary (core/sara.py)
+    (("db4", "db5"), 2, (128, 256)),                    # tests/test_wavelets.py:72-75
+    (("db1",), 1, (512, 128)),
+    (("db8", "self", "db6"), 3, (250, 300)),            # sizes that go odd at deeper levels
+])
+def test_psi_dot_hdot_vs_oracle(bases, nlevel, shape):
+    from pfb_imaging_amd.operators.psi import Psi, PsiNocopyt
+
+    nband = 2
+    nx, ny = shape
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((nband, nx, ny))
+    o = opsi.Psi(nband, nx, ny, bases, nlevel)
+    g = PsiNocopyt(nband, nx, ny, bases, nlevel, nthreads=1)
+    assert (g.nxmax, g.nymax, g.nbasis) == (o.nxmax, o.nymax, o.nbasis)
+    a_ref = np.zeros((nband, o.nbasis, o.nxmax, o.nymax))
+    o.dot(x, a_ref)
+    a = np.full_like(a_ref, np.nan)  # every element must be written
+    g.dot(x, a)
+    assert rel(a, a_ref) < 1e-14
+    coeffs = rng.standard_normal(a_ref.shape)
+    x_ref = np.zeros_like(x)
+    o.hdot(coeffs, x_ref)
+    xo = np.full_like(x, np.nan)
+    keep = coeffs.copy()
+    g.hdot(coeffs, xo)
+    assert rel(xo, x_ref) < 1e-14
+    assert np.array_equal(coeffs, keep)  # hdot must not touch its input (psi.py "to avoid overwriting coeffs")
+    # perfect reconstruction: Psi Psi^H = nbasis * I (orthonormal bases, zero-padding mode keeps all coefficients)
+    back = np.zeros_like(x)
+    g.hdot(a, back)
+    assert rel(back / len(bases), x) < 1e-13
+    # adjointness
+    assert abs(np.vdot(a, coeffs) - np.vdot(x, xo)) < 1e-10 * abs(np.vdot(x, xo))
+    # the older transposed layout
+    gt = Psi(nband, nx, ny, bases, nlevel, nthreads=1)
+    at = np.zeros((nband, o.nbasis, o.nymax, o.nxmax))
+    gt.dot(x, at)
+    assert np.array_equal(at, a.transpose(0, 1, 3, 2))
+    xt = np.zeros_like(x)
+    gt.hdot(np.ascontiguousarray(coeffs.transpose(0, 1, 3, 2)), xt)
+    assert rel(xt, xo) < 1e-15
+
+
+def test_psi_errors():
+    from pfb_imaging_amd.operators.psi import PsiNocopyt
+
+    with pytest.raises(ValueError):
+        PsiNocopyt(1, 64, 64, ("db9",), 2)
+    with pytest.raises(ValueError):
+        PsiNocopyt(1, 63, 64, ("db1",), 2)     # odd image size
+    with pytest.raises(ValueError):
+        PsiNocopyt(1, 16, 16, ("db8",), 3)     # level not possible
+    p = PsiNocopyt(1, 64, 64, ("db2",), 2)
+    with pytest.raises(ValueError):
+        p.dot(np.zeros((1, 64, 64)), np.zeros((1, 1, 10, 10)))
+
+
+def test_dual_update_prox_positivity():
+    from pfb_imaging_amd import prox
+
+    rng = np.random.default_rng(8)
+    nband, nbasis, n1, n2 = 3, 4, 37, 29
+    vp = rng.standard_normal((nband, nbasis, n1, n2))
+    v = rng.standard_normal((nband, nbasis, n1, n2))
+    w = np.abs(rng.standard_normal((nbasis, n1, n2))) + 0.1
+    w[0, 0, :5] = 0.0  # zero threshold
+    ref = opsi.dual_update(vp, v.copy(), 0.7, 1.3, w)
+    got = v.copy()
+    prox.dual_update_numba_fast(vp, got, 0.7, 1.3, w)
+    assert rel(got, ref) < 1e-15
+    # numpy form of the reference (prox_21m.py:61-70): v = vtilde - sigma prox(vtilde / sigma, lam / sigma)
+    vt = vp + 1.3 * v
+    ref2 = vt - 1.3 * opsi.prox_21m(vt / 1.3, 0.7 / 1.3, weight=w)
+    assert rel(got, ref2) < 1e-13
+    assert rel(prox.prox_21m(v, 0.4, weight=w), opsi.prox_21m(v, 0.4, weight=w)) < 1e-15
+    res = np.empty_like(v)
+    prox.prox_21m_numba(v, res, 0.7, 1.3, w)
+    assert rel(res, opsi.prox_21m(v / 1.3, 0.7 / 1.3, weight=w)) < 1e-15
+    x = rng.standard_normal((nband, 33, 21))
+    a, b = x.copy(), x.copy()
+    prox.positivity(a)
+    assert np.array_equal(a, opsi.positivity(x.copy()))
+    prox.positivity_band(b)
+    assert np.array_equal(b, opsi.positivity_band(x.copy()))
+    assert prox.positivity_prox(0) is None and prox.positivity_prox(2) is prox.positivity_band
+    with pytest.raises(ValueError):
+        prox.positivity_prox(3)

@@ -191,3 +191,38 @@ def test_kernel_table_and_poly():
         approx = np.polynomial.polynomial.polyval(2 * f - 1, kt[a])
         assert np.abs(exact - approx).max() < 1e-11
     assert owg.good_size(11468) == 11520 and owg.good_size(1025, True) == 1080
+
+
+def test_psi_oracle_pins():
+    """oracle/psi.py has no reference fixtures (PyWavelets is not installed): it is pinned by the algebra the
+    reference's own tests check (tests/test_wavelets.py:72-132: perfect reconstruction) plus adjointness,
+    hand-worked Haar values and the bookkeeping formulas of operators/psi.py:73-113."""
+    from oracle import psi as opsi
+
+    # Haar by hand: pywt.dwt([1,2,3,4], 'db1') -> cA = [3, 7]/sqrt2, cD = [-1, -1]/sqrt2
+    lo, hi, rlo, rhi = opsi.filters("db1")
+    x = np.array([[1.0, 2.0, 3.0, 4.0]])
+    assert np.allclose(opsi.down_conv(x, lo, 1), np.array([[3.0, 7.0]]) / np.sqrt(2))
+    assert np.allclose(opsi.down_conv(x, hi, 1), np.array([[-1.0, -1.0]]) / np.sqrt(2))
+    # db2 analytic scaling filter
+    s3 = np.sqrt(3.0)
+    assert np.allclose(opsi.filters("db2")[2], np.array([1 + s3, 3 + s3, 3 - s3, 1 - s3]) / (4 * np.sqrt(2)), atol=1e-15)
+    # bookkeeping for 64 x 48, db2, 3 levels (psi.py:73-113 by hand: 33/18/10 and 25/14/8 coefficients per level)
+    bk = opsi.Bookkeeping(64, 48, ("self", "db2"), 3)
+    assert list(bk.sx[0]) == [33, 18, 10] and list(bk.sy[0]) == [25, 14, 8]
+    assert bk.ntotx[0] == 71 and bk.ntoty[0] == 55 and (bk.nxmax, bk.nymax) == (71, 55)
+    assert list(bk.ix[0, :, 1]) == [71, 38, 20] and list(bk.spx[0]) == [64, 34, 18]
+    rng = np.random.default_rng(0)
+    for bases, nl, shape in ((("self", "db1", "db2", "db3"), 3, (64, 48)), (("db4", "db5"), 2, (128, 256))):
+        nx, ny = shape
+        P = opsi.Psi(2, nx, ny, bases, nl)
+        x = rng.standard_normal((2, nx, ny))
+        a = np.zeros((2, P.nbasis, P.nxmax, P.nymax))
+        P.dot(x, a)
+        xr = np.zeros_like(x)
+        P.hdot(a, xr)
+        assert np.abs(xr / len(bases) - x).max() < 1e-13
+        b = rng.standard_normal(a.shape)
+        xb = np.zeros_like(x)
+        P.hdot(b, xb)
+        assert abs(np.vdot(a, b) - np.vdot(x, xb)) < 1e-10 * abs(np.vdot(x, xb))
