@@ -11,8 +11,9 @@ with one RCCL all-reduce of the cube (each band is produced by exactly one rank)
 (core/deconv.py:320-321).  Without a communicator all bands run in-process on the current
 GPU, like the reference's ``nband == 1`` local path (band_worker.py:220-223).
 
-The wavelet role (``init_psi`` / ``psi_dot`` / ``psi_hdot``) belongs to the SARA dictionary,
-which SURVEY.md section 8(f) ranks after this path; it raises NotImplementedError.
+The wavelet role (``init_psi`` / ``psi_dot`` / ``psi_hdot``, band_worker.py:144-163, 291-301) runs the
+SARA dictionary of ``operators.psi`` on the band's GPU; ``dual_update`` is the band-sharded form of
+``dual_update_numba_fast`` (prox/prox_21m.py:105-135): the band sum is completed with ONE all-reduce.
 """
 
 import numpy as np
@@ -100,9 +101,22 @@ class _BandWorkerImpl:
             return self._dirty - np.zeros_like(self._dirty)
         return self._dirty - self._resid.convim(model)
 
-    # --- wavelet role: next component ---
+    # --- wavelet role (band_worker.py:144-163) ---
     def init_psi(self, nx, ny, bases, nlevel):
-        raise NotImplementedError("the SARA wavelet dictionary is not part of the measurement-operator path")
+        from .psi import PsiBand
+
+        self._psib = PsiBand(nx, ny, tuple(bases), nlevel)
+        self._alphao = np.empty((self._psib.nbasis, self._psib.nxmax, self._psib.nymax))
+        self._xo = np.empty((nx, ny))
+        return int(self._psib.nxmax), int(self._psib.nymax)
+
+    def psi_dot(self, x):
+        self._psib.dot(x, self._alphao)
+        return self._alphao
+
+    def psi_hdot(self, alpha):
+        self._psib.hdot(alpha, self._xo)
+        return self._xo
 
     # --- telemetry ---
     def get_mem(self):
@@ -172,9 +186,32 @@ class BandWorkerPool:
             out[b] = res
         return self._exchange(out)
 
-    # --- Psi role ---
+    # --- Psi role (band_worker.py:291-301) ---
     def init_psi(self, nx, ny, bases, nlevel):
-        raise NotImplementedError("the SARA wavelet dictionary is not part of the measurement-operator path")
+        shapes = self._map("init_psi", [(nx, ny, tuple(bases), nlevel)] * self.nband)
+        self._psi_shape = next(iter(shapes.values()))
+        return self._psi_shape  # (nxmax, nymax), identical across bands
+
+    def psi_dot(self, x, alphao):
+        out = np.zeros(alphao.shape, dtype=np.float64)
+        for b, res in self._map("psi_dot", [(x[b],) for b in range(self.nband)]).items():
+            out[b] = res
+        alphao[...] = self._exchange(out)
+
+    def psi_hdot(self, alpha, xo):
+        out = np.zeros(xo.shape, dtype=np.float64)
+        for b, res in self._map("psi_hdot", [(alpha[b],) for b in range(self.nband)]).items():
+            out[b] = res
+        xo[...] = self._exchange(out)
+
+    def dual_update(self, vp, v, lam, sigma=1.0, weight=None):
+        """``dual_update_numba_fast`` (prox/prox_21m.py:105-135) over cubes ``(nband, nbasis, n1, n2)``, in place
+        on ``v``.  Each rank updates the bands it owns; the band sum of vtilde is completed with one
+        all-reduce (the only collective of the primal-dual iteration), after which every rank
+        holds the full updated cube again."""
+        from ..prox import dual_update_bands
+
+        dual_update_bands(vp, v, lam, sigma, weight, comm=self.comm, bands=self.local)
 
     # --- exact residual role ---
     def residual(self, model, cell_rad, epsilon=1e-7, do_wgridding=True, double_accum=True):

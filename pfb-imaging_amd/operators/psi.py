@@ -110,6 +110,29 @@ class Psi(_PsiCube):
     _transposed = True
 
 
+class PsiNocopytRay:
+    """Facade over a ``BandWorkerPool`` (psi.py:670-711): one band per GPU process instead of one Ray actor
+    per band; cubes are (nband, nbasis, nxmax, nymax)."""
+
+    def __init__(self, nband, nx, ny, bases, nlevel, nthreads=1, workers=None):
+        from .band_worker import BandWorkerPool
+
+        self.nband, self.nx, self.ny = nband, nx, ny
+        self.nbasis, self.nthreads = len(bases), nthreads
+        if workers is None:
+            workers = BandWorkerPool(nband, nthreads)
+        elif workers.nband != nband:
+            raise ValueError(f"workers pool has {workers.nband} bands, expected {nband}")
+        self._pool = workers
+        self.nxmax, self.nymax = self._pool.init_psi(nx, ny, bases, nlevel)
+
+    def dot(self, x, alphao):
+        self._pool.psi_dot(x, alphao)
+
+    def hdot(self, alpha, xo):
+        self._pool.psi_hdot(alpha, xo)
+
+
 class IdentityPsi:
     """psi.py:714-734 (pure bookkeeping, no arithmetic)."""
 

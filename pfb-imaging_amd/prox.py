@@ -34,6 +34,64 @@ def dual_update_numba_fast(vp, v, lam, sigma=1.0, weight=None):
 dual_update_numba = dual_update_numba_fast
 
 
+def _vtilde_sum_gpu(vp_loc, v_loc, sigma):
+    """GPU phase 1 on this rank's bands: v_loc <- vp_loc + sigma v_loc (in place), returns the local band sum."""
+    from ._lib import DeviceArray
+
+    nb = v_loc.shape[0]
+    n = v_loc.size // max(nb, 1)
+    dvp, dv = DeviceArray.from_host(vp_loc), DeviceArray.from_host(v_loc)
+    ds = DeviceArray((n,), np.float64)
+    check(lib().pfbhip_l21_vtilde_sum_dev(dvp.ptr, dv.ptr, i64(nb), i64(n), f64(sigma), ds.ptr))
+    dv.download(v_loc)
+    s = ds.download()
+    for d in (dvp, dv, ds):
+        d.free()
+    return s.reshape(v_loc.shape[1:])
+
+
+def _scale_gpu(v_loc, lam, weight, total):
+    """GPU phase 2 on this rank's bands, given the band sum over ALL bands."""
+    from ._lib import DeviceArray
+
+    nb = v_loc.shape[0]
+    n = v_loc.size // max(nb, 1)
+    dv, dw, ds = DeviceArray.from_host(v_loc), DeviceArray.from_host(weight), DeviceArray.from_host(total)
+    check(lib().pfbhip_l21_scale_dev(dv.ptr, i64(nb), i64(n), f64(lam), dw.ptr, ds.ptr))
+    dv.download(v_loc)
+    for d in (dv, dw, ds):
+        d.free()
+
+
+def dual_update_bands(vp, v, lam, sigma=1.0, weight=None, comm=None, bands=None, phases=None):
+    """Band-sharded ``dual_update_numba_fast`` over full cubes ``(nband, nbasis, n1, n2)``, in place on ``v``.
+
+    Every rank holds the full cubes (as the reference's driver does); rank r computes the bands in ``bands``.
+    The band sum of vtilde -- the one quantity that couples the bands -- is completed with ONE all-reduce
+    (`allreduce(sum)` of the band-sum inside the l21 dual update each PD iteration); a second
+    all-reduce re-assembles the updated cube (each band is produced by exactly one rank).
+    ``phases`` lets the CPU tests substitute the two device phases."""
+    if comm is None or comm.world_size == 1:
+        if phases is None:
+            dual_update_numba_fast(vp, v, lam, sigma, weight)
+            return
+    v = _inplace(v)
+    vtilde_sum, scale = phases if phases is not None else (_vtilde_sum_gpu, _scale_gpu)
+    if phases is None:
+        _lib.require_gpu()
+    idx = list(range(v.shape[0])) if bands is None else list(bands)
+    w = np.ones(v.shape[1:]) if weight is None else as_c(np.broadcast_to(weight, v.shape[1:]), np.float64)
+    v_loc = np.ascontiguousarray(v[idx])
+    vp_loc = np.ascontiguousarray(np.asarray(vp, dtype=np.float64)[idx])
+    local = vtilde_sum(vp_loc, v_loc, sigma) if idx else np.zeros(v.shape[1:])
+    total = local if comm is None else comm.allreduce_sum(local).reshape(local.shape)
+    if idx:
+        scale(v_loc, lam, w, np.ascontiguousarray(total))
+    out = np.zeros_like(v)
+    out[idx] = v_loc
+    v[...] = out if comm is None else comm.allreduce_sum(out).reshape(v.shape)
+
+
 def prox_21m(v, sigma, weight=1.0, axis=0):
     """prox_{sigma ||.||_21}(v) with the band axis first (prox_21m.py:5-26); returns a new array."""
     _lib.require_gpu()

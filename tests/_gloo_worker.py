@@ -35,6 +35,23 @@ class FakeWorker:
     def residual(self, model, cell_rad, epsilon, do_wgridding, double_accum):
         return self.dirty - self.scale * model
 
+    # wavelet role: the oracle's dictionary stands in for the GPU one
+    def init_psi(self, nx, ny, bases, nlevel):
+        from oracle import psi as opsi
+
+        self._psi = opsi.Psi(1, nx, ny, bases, nlevel)
+        return self._psi.nxmax, self._psi.nymax
+
+    def psi_dot(self, x):
+        out = np.zeros((1, self._psi.nbasis, self._psi.nxmax, self._psi.nymax))
+        self._psi.dot(x[None], out)
+        return out[0]
+
+    def psi_hdot(self, alpha):
+        out = np.zeros((1, self._psi.nx, self._psi.ny))
+        self._psi.hdot(alpha[None], out)
+        return out[0]
+
 
 def main():
     comm = BandComm.from_env(transport="gloo")
@@ -77,6 +94,39 @@ def main():
         np.testing.assert_allclose(mfs, ref.sum(axis=0) / 4.0, rtol=1e-13)
     else:
         assert mfs is None
+    # Psi role + band-sharded l21 dual update (config-4 style): one all-reduce completes the band sum
+    from oracle import psi as opsi
+    from pfb_imaging_amd.operators.psi import PsiNocopytRay
+    from pfb_imaging_amd.prox import dual_update_bands
+
+    px, py = 16, 12
+    psi = PsiNocopytRay(nband, px, py, ("self", "db1", "db2"), 2, workers=pool)
+    full_psi = opsi.Psi(nband, px, py, ("self", "db1", "db2"), 2)
+    assert (psi.nxmax, psi.nymax) == (full_psi.nxmax, full_psi.nymax)
+    img = rng.standard_normal((nband, px, py))
+    alpha = np.zeros((nband, 3, psi.nxmax, psi.nymax))
+    psi.dot(img, alpha)
+    ref_alpha = np.zeros_like(alpha)
+    full_psi.dot(img, ref_alpha)
+    np.testing.assert_allclose(alpha, ref_alpha, rtol=0, atol=1e-13)
+    back = np.zeros_like(img)
+    psi.hdot(alpha, back)
+    np.testing.assert_allclose(back, 3 * img, rtol=0, atol=1e-12)
+    vp = rng.standard_normal(alpha.shape)
+    wgt = np.abs(rng.standard_normal(alpha.shape[1:])) + 0.05
+
+    def vtilde_sum(vp_loc, v_loc, sigma):  # CPU stand-ins of the two device phases (oracle arithmetic)
+        v_loc[...] = vp_loc + sigma * v_loc
+        return v_loc.sum(axis=0)
+
+    def scale(v_loc, lam, w, total):
+        a = np.abs(total)
+        v_loc *= np.where(a > lam * w, lam * w / np.where(a > 0, a, 1.0), 1.0)[None]
+
+    v = alpha.copy()
+    dual_update_bands(vp, v, 0.8, 1.7, wgt, comm=comm, bands=pool.local, phases=(vtilde_sum, scale))
+    np.testing.assert_allclose(v, opsi.dual_update(vp, alpha.copy(), 0.8, 1.7, wgt), rtol=0, atol=1e-13)
+
     # single band sharded by row blocks (config-5 style): partial images are summed, degridding is local
     from oracle import wgridder as owg
     from pfb_imaging_amd.parallel import RowShardedGridder, row_block
