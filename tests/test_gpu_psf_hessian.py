@@ -224,8 +224,7 @@ def test_band_pool_residual_and_mfs():
                                    atol=1e-9)
     mfs = pool.residual_mfs(model, 1.0e-6, wsum=3.0)
     np.testing.assert_allclose(mfs, res.sum(axis=0) / 3.0, rtol=1e-12, atol=1e-12)
-    with pytest.raises(NotImplementedError):
-        pool.init_psi(nx, ny, ["self"], 2)
+    assert pool.init_psi(nx, ny, ["self"], 2) == (nx, ny)  # the wavelet role (tests/test_gpu_psi.py)
 
 
 @pytest.mark.parametrize("center_offset", [(0.0, 0.0), (0.1, -0.17), (0.2, 0.5), (-0.1, 0.2), (-0.15, -0.2)])
