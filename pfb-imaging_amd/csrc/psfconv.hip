@@ -21,6 +21,7 @@
 
 #include "common.hpp"
 #include "psffft_api.hpp"
+#include "pipeline_api.hpp"
 #include "devcg.hpp"
 
 namespace pfbhip {
@@ -202,6 +203,20 @@ struct pfbhip_psfconv {
         PFB_HIP(hipGetLastError());
     }
 };
+
+namespace pfbhip {
+hipStream_t psfconv_stream(pfbhip_psfconv *p) { return p->stream; }
+void psfconv_geometry(const pfbhip_psfconv *p, int64_t *nx, int64_t *ny)
+{
+    *nx = p->nx;
+    *ny = p->ny;
+}
+void psfconv_apply_async(pfbhip_psfconv *p, const double *x_dev, int64_t psf_slot, int64_t beam_slot, int mode, double shift,
+                         double scale, double eta, int accumulate, double *out_dev)
+{
+    p->apply(x_dev, psf_slot, beam_slot, mode, shift, scale, eta, accumulate, out_dev);
+}
+}  // namespace pfbhip
 
 extern "C" {
 

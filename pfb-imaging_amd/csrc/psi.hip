@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "pipeline_api.hpp"
 
 namespace pfbhip {
 
@@ -310,6 +311,42 @@ struct pfbhip_psi {
     double *img2() { return img.p; }
     void swap_img() {}
 };
+
+namespace pfbhip {
+hipStream_t psi_swap_stream(pfbhip_psi *p, hipStream_t st)
+{
+    hipStream_t prev = p->stream;
+    p->stream = st;
+    return prev;
+}
+void psi_geometry(const pfbhip_psi *p, int64_t *nx, int64_t *ny, int *nbasis, int64_t *nxmax, int64_t *nymax)
+{
+    *nx = p->nx;
+    *ny = p->ny;
+    *nbasis = p->nbasis;
+    *nxmax = p->nxmax;
+    *nymax = p->nymax;
+}
+void psi_dot_async(pfbhip_psi *p, const double *x_dev, double *alpha_dev) { p->dot(x_dev, alpha_dev); }
+void l21_vtilde_async(const double *vp_dev, double *v_dev, int64_t nband, int64_t n, double sigma, double *sum_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_l21_vtilde, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, st, vp_dev, v_dev, int(nband), n, sigma, sum_dev);
+    PFB_HIP(hipGetLastError());
+}
+void l21_scale_async(double *v_dev, int64_t nband, int64_t n, double lam, const double *weight_dev, const double *sum_dev,
+                     hipStream_t st)
+{
+    hipLaunchKernelGGL(k_l21_scale, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, st, v_dev, int(nband), n, lam, weight_dev,
+                       sum_dev);
+    PFB_HIP(hipGetLastError());
+}
+void positivity_async(double *x_dev, int64_t nband, int64_t n, int mode, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_positivity, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, st, x_dev, int(nband), n, mode);
+    PFB_HIP(hipGetLastError());
+}
+void psi_hdot_async(pfbhip_psi *p, const double *alpha_dev, double *x_dev) { p->hdot(alpha_dev, x_dev); }
+}  // namespace pfbhip
 
 extern "C" {
 

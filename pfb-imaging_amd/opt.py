@@ -1,0 +1,174 @@
+"""The backward (primal-dual) step of the SARA minor cycle on the GPU.
+
+Mirrors /root/reference/src/pfb_imaging/opt/primal_dual.py:303-448 (``PrimalDual``) and
+prox/l21.py:15-50 (``L21``).  When the gradient is the closure of the forward-backward splitting,
+``grad(x) = -hess.dot(xtilde - x) / gamma`` (core/sara.py:288-289, deconv/pfb.py:158-161), expressed as a
+``PsfGrad`` over a device-resident ``HessPSF``, and the dictionary is this package's ``Psi`` / ``PsiNocopyt``,
+``solve`` runs the whole loop on the device (``pfbhip_primal_dual``: one scalar round trip per iteration).
+Any other gradient callable runs the reference's loop with the GPU dictionary / dual update and the
+reference's own host-side vector steps.
+"""
+
+import ctypes as ct
+
+import numpy as np
+
+from . import _lib
+from ._lib import PDInfo, as_c, check, cint, f64, i64, lib, ptr
+from .operators.psi import Psi, PsiNocopyt
+from .prox import dual_update_numba_fast, prox_21m_numba
+
+
+class L21:
+    """R(x) = ||W Psi^T x||_{2,1}, 2-norm over the band axis (prox/l21.py:15-50)."""
+
+    def __init__(self, psi, bases, nu=1.0, rmsfactor=1.0, alpha=2.0):
+        for name in ("dot", "hdot", "nband", "nbasis", "nxmax", "nymax"):
+            if not hasattr(psi, name):
+                raise TypeError(f"psi does not satisfy the PsiOperator protocol (missing {name})")
+        self.psi = psi
+        self.nu = nu
+        self.bases = tuple(bases)
+        self.rmsfactor = rmsfactor
+        self.alpha = alpha
+        self.l1weight = np.ones(self.coeff_shape()[1:])
+
+    def coeff_shape(self):
+        """(nband, nbasis, n1, n2) in the layout of ``psi`` (the reference allocates (.., nymax, nxmax))."""
+        p = self.psi
+        if isinstance(p, PsiNocopyt):
+            return (p.nband, p.nbasis, p.nxmax, p.nymax)
+        return (p.nband, p.nbasis, p.nymax, p.nxmax)
+
+    def prox(self, v, vout, lam, sigma=1.0):
+        prox_21m_numba(v, vout, lam, sigma=sigma, weight=self.l1weight)
+
+    def dual_update(self, vp, v, lam, sigma=1.0):
+        dual_update_numba_fast(vp, v, lam, sigma=sigma, weight=self.l1weight)
+
+
+class PsfGrad:
+    """grad(x) = -hess.dot(xtilde - x) / gamma with ``hess`` a PSF-approximate Hessian (HessPSF)."""
+
+    def __init__(self, hess, xtilde, gamma=1.0):
+        self.hess, self.gamma = hess, float(gamma)
+        self.xtilde = np.ascontiguousarray(xtilde, dtype=np.float64)
+
+    def __call__(self, x):
+        return -self.hess.dot(self.xtilde - x) / self.gamma
+
+
+class PrimalDual:
+    """primal_dual.py:303-448: same constructor, ``setup`` / ``set_grad`` / ``reset`` / ``solve`` contract."""
+
+    def __init__(self, tol=1e-5, maxit=1000, report_freq=10, verbosity=1, gamma=1.0, sigma=None, on_converge=None,
+                 primal_prox=None):
+        self.tol, self.maxit, self.report_freq, self.verbosity = tol, maxit, report_freq, verbosity
+        self.gamma, self._sigma_opt = gamma, sigma
+        self.on_converge, self.primal_prox = on_converge, primal_prox
+        self._grad = self._reg = self._v = None
+        self.last = None
+
+    def setup(self, prox, hessnorm):
+        if not all(hasattr(prox, a) for a in ("psi", "nu", "prox")):
+            raise TypeError("prox does not satisfy the Regulariser protocol")
+        self._reg = prox
+        self.hessnorm = hessnorm
+        nu = prox.nu
+        sigma = self._sigma_opt
+        if sigma is None:
+            sigma = hessnorm / (2.0 * self.gamma) / nu
+        self.sigma = sigma
+        self.tau = 0.98 / (hessnorm / (2.0 * self.gamma) + sigma * nu**2)
+        shape = prox.coeff_shape() if hasattr(prox, "coeff_shape") else (prox.psi.nband, prox.psi.nbasis, prox.psi.nymax,
+                                                                          prox.psi.nxmax)
+        self._v = np.zeros(shape)
+
+    def set_grad(self, grad):
+        self._grad = grad
+
+    def reset(self):
+        if self._v is not None:
+            self._v[...] = 0.0
+
+    # ---- device-resident loop --------------------------------------------------------------
+    def _device_path(self):
+        from .operators.hessian import HessPSF
+        from .prox import positivity, positivity_band
+
+        g, reg = self._grad, self._reg
+        if not (isinstance(g, PsfGrad) and isinstance(g.hess, HessPSF) and isinstance(reg, L21)):
+            return None
+        if not isinstance(reg.psi, (Psi, PsiNocopyt)) or self.on_converge is not None:
+            return None
+        mode = {None: 0, positivity: 1, positivity_band: 2}.get(self.primal_prox, None)
+        return mode
+
+    def _solve_device(self, x, lam, mode):
+        hess, reg, psi = self._grad.hess, self._reg, self._reg.psi
+        nband = psi.nband
+        transposed = isinstance(psi, Psi)
+        v = self._v.transpose(0, 1, 3, 2) if transposed else self._v
+        w = reg.l1weight.T if False else (reg.l1weight.transpose(0, 2, 1) if transposed else reg.l1weight)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        w = np.ascontiguousarray(np.broadcast_to(w, v.shape[1:]), dtype=np.float64)
+        xs = np.ascontiguousarray(x, dtype=np.float64).copy()
+        nparts = np.ones(nband, dtype=np.int64)
+        psf_slots = np.arange(nband, dtype=np.int64)
+        beam_slots = np.array([-1 if hess.beam[b] is None else b for b in range(nband)], dtype=np.int64)
+        scale = np.ones(nband)
+        eta = np.ascontiguousarray(hess.eta, dtype=np.float64)
+        info = PDInfo()
+        check(lib().pfbhip_primal_dual(psi._band._h, hess._plan._h, i64(nband), ptr(nparts), ptr(psf_slots), ptr(beam_slots),
+                                       ptr(scale), ptr(eta), ptr(self._grad.xtilde), f64(self._grad.gamma), ptr(xs), ptr(v),
+                                       ptr(w), f64(lam), f64(self.sigma), f64(self.tau), cint(mode), f64(self.tol),
+                                       cint(self.maxit), ct.byref(info)))
+        self._v[...] = v.transpose(0, 1, 3, 2) if transposed else v
+        self.last = dict(iters=info.iters, status=info.status, eps=info.eps)
+        x[...] = xs
+        return x
+
+    # ---- the reference's loop (any gradient callable) ----------------------------------------
+    def _dual_step(self, xp, v, vp, lam):
+        reg = self._reg
+        reg.psi.dot(xp, v)
+        if hasattr(reg, "dual_update"):
+            reg.dual_update(vp, v, lam, sigma=self.sigma)
+        else:
+            vtilde = vp + self.sigma * v
+            reg.prox(vtilde, v, lam, sigma=self.sigma)
+            np.subtract(vtilde, self.sigma * v, out=v)
+
+    def solve(self, x, lam):
+        if self._reg is None:
+            raise RuntimeError("regulariser not bound; call setup() before solve()")
+        if self._grad is None:
+            raise RuntimeError("grad not set; call set_grad() before solve()")
+        _lib.require_gpu()
+        mode = self._device_path()
+        if mode is not None:
+            return self._solve_device(x, lam, mode)
+        xp = x.copy()
+        v = self._v
+        vp = v.copy()
+        xout = np.zeros_like(x)
+        eps, k = 1.0, 0
+        for k in range(self.maxit):
+            self._dual_step(xp, v, vp, lam)
+            vp[...] = 2.0 * v - vp
+            self._reg.psi.hdot(vp, xout)
+            xout += self._grad(xp)
+            x[...] = xp - self.tau * xout
+            if self.primal_prox is not None:
+                self.primal_prox(x)
+            if x.any():
+                eps = float(np.sqrt(((x - xp) ** 2).sum() / max((x**2).sum(), 1e-12)))
+            else:
+                eps = 1.0
+            if eps < self.tol:
+                if self.on_converge is None or self.on_converge(x, k, eps):
+                    break
+            np.copyto(xp, x)
+            np.copyto(vp, v)
+        self.last = dict(iters=k, status=0 if eps < self.tol else 1, eps=eps)
+        return x

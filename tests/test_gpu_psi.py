@@ -134,3 +134,85 @@ def test_band_pool_psi_role_and_dual_update():
     v2 = a.copy()
     pool.dual_update(vp, v2, 0.6, 1.4, w)
     assert np.array_equal(v2, v)
+
+
+def _oracle_pd(x, v, lam, psi, weight, hess, xtilde, gamma, sigma, tau, tol, maxit, positivity):
+    """PrimalDual.solve (primal_dual.py:406-448) in numpy on the oracle's dictionary (x-first layout)."""
+    x, v = x.copy(), v.copy()
+    xp, vp = x.copy(), v.copy()
+    xout = np.zeros_like(x)
+    eps, k = 1.0, 0
+    for k in range(maxit):
+        psi.dot(xp, v)
+        opsi.dual_update(vp, v, lam, sigma, weight)
+        vp = 2.0 * v - vp
+        psi.hdot(vp, xout)
+        xout = xout - hess(xtilde - xp) / gamma
+        x = xp - tau * xout
+        if positivity == 1:
+            opsi.positivity(x)
+        elif positivity == 2:
+            opsi.positivity_band(x)
+        eps = np.sqrt(((x - xp) ** 2).sum() / max((x**2).sum(), 1e-12)) if x.any() else 1.0
+        if eps < tol:
+            break
+        xp, vp = x.copy(), v.copy()
+    return x, v, k, eps
+
+
+@pytest.mark.parametrize("layout,positivity,use_beam", [("nocopyt", 0, True), ("psi", 1, False), ("nocopyt", 2, True)])
+def test_primal_dual_device_loop(layout, positivity, use_beam):
+    """The device-resident backward step == the reference's loop on the oracle pieces, and == the generic
+    (callable-gradient) path of this package."""
+    from oracle import fftconv
+    from pfb_imaging_amd import prox
+    from pfb_imaging_amd.operators.hessian import HessPSF
+    from pfb_imaging_amd.operators.psi import Psi, PsiNocopyt
+    from pfb_imaging_amd.opt import L21, PrimalDual, PsfGrad
+
+    nband, nx, ny, nxp, nyp = 2, 64, 48, 128, 96
+    bases, nlevel = ("self", "db1", "db2"), 2
+    rng = np.random.default_rng(21)
+    psf = np.zeros((nband, nxp, nyp))
+    psf[:, 0, 0] = 1.0
+    psf += 0.02 * rng.standard_normal(psf.shape)
+    abspsf = np.abs(np.fft.rfft2(psf, axes=(1, 2)))
+    beam = 0.8 + 0.2 * rng.random((nband, nx, ny)) if use_beam else None
+    eta = np.array([0.05, 0.1])
+    hess = HessPSF(nx, ny, abspsf, beam=beam, eta=eta)
+    model = np.abs(rng.standard_normal((nband, nx, ny))) * (rng.random((nband, nx, ny)) > 0.9)
+    xtilde = model + 0.3 * rng.standard_normal(model.shape)
+    # a valid bound on ||H|| (an underestimate makes the iteration expansive: one-step parity stays exact but
+    # rounding differences between the FFT libraries then double every iteration under the positivity clamp)
+    hessnorm = float(abspsf.max() * (beam.max() ** 2 if beam is not None else 1.0) + eta.max())
+    gamma, lam = 1.0, 0.02
+    cls = PsiNocopyt if layout == "nocopyt" else Psi
+    psi = cls(nband, nx, ny, bases, nlevel, 1)
+    reg = L21(psi, bases, nu=np.sqrt(len(bases)))  # ||Psi||: Psi Psi^H = nbasis I
+    reg.l1weight = 0.5 + rng.random(reg.l1weight.shape)
+    pp = prox.positivity_prox(positivity)
+    pd = PrimalDual(tol=1e-6, maxit=40, verbosity=0, gamma=gamma, primal_prox=pp)
+    pd.setup(reg, hessnorm)
+    pd.set_grad(PsfGrad(hess, xtilde, gamma))
+    assert pd._device_path() == positivity
+    got = pd.solve(model.copy(), lam)
+    # oracle loop (x-first layout)
+    o = opsi.Psi(nband, nx, ny, bases, nlevel)
+    w = reg.l1weight if layout == "nocopyt" else reg.l1weight.transpose(0, 2, 1)
+    v0 = np.zeros((nband, o.nbasis, o.nxmax, o.nymax))
+    href = lambda z: fftconv.hess_psf_dot(z, abspsf, nyp, beam=beam, eta=eta)
+    xr, vr, kr, er = _oracle_pd(model, v0, lam, o, w, href, xtilde, gamma, pd.sigma, pd.tau, 1e-6, 40, positivity)
+    assert pd.last["iters"] == kr
+    assert rel(got, xr) < 1e-9
+    vgot = pd._v if layout == "nocopyt" else pd._v.transpose(0, 1, 3, 2)
+    # the dual integrates sigma Psi^H x_k over the iterations: rounding differences of the two FFT libraries in x
+    # (1e-10 after 40 iterations) show up ~100x larger relative to the (small) unclipped dual coefficients
+    assert rel(vgot, vr) < 1e-6
+    # generic path (plain callable): same iterates
+    pd2 = PrimalDual(tol=1e-6, maxit=40, verbosity=0, gamma=gamma, primal_prox=pp)
+    pd2.setup(reg, hessnorm)
+    g = PsfGrad(hess, xtilde, gamma)
+    pd2.set_grad(lambda z: g(z))
+    assert pd2._device_path() is None
+    got2 = pd2.solve(model.copy(), lam)
+    assert rel(got2, xr) < 1e-7 and pd2.last["iters"] == kr
