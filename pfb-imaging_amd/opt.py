@@ -32,6 +32,8 @@ class L21:
         self.rmsfactor = rmsfactor
         self.alpha = alpha
         self.l1weight = np.ones(self.coeff_shape()[1:])
+        self._outvar = None
+        self._rms_comps = None
 
     def coeff_shape(self):
         """(nband, nbasis, n1, n2) in the layout of ``psi`` (the reference allocates (.., nymax, nxmax))."""
@@ -42,6 +44,34 @@ class L21:
 
     def prox(self, v, vout, lam, sigma=1.0):
         prox_21m_numba(v, vout, lam, sigma=sigma, weight=self.l1weight)
+
+    # ---- l1 reweighting (prox/l21.py:52-88, utils/misc.py:742-755): host bookkeeping on the GPU analysis ----
+    @property
+    def reweight_active(self):
+        return self._rms_comps is not None
+
+    def _band_sum(self, x):
+        if self._outvar is None:
+            self._outvar = np.zeros(self.coeff_shape())
+        self.psi.dot(x, self._outvar)
+        return np.sum(self._outvar, axis=0)
+
+    def init_reweighting(self, update):
+        """Estimate per-basis component rms from the update and arm reweighting (l21.py:56-78)."""
+        tmp = self._band_sum(update)
+        rms = np.ones(self.psi.nbasis, dtype=float)
+        for i in range(self.psi.nbasis):
+            nonzero = tmp[i][tmp[i] != 0]
+            if nonzero.size:
+                rms[i] = np.std(nonzero)
+        self._rms_comps = rms
+
+    def update_weights(self, x):
+        """l1weight = (1 + rmsfactor) / (1 + |sum_band Psi^T x|^alpha / rms^alpha) (misc.py:742-755)."""
+        if self._rms_comps is None:
+            raise RuntimeError("reweighting not initialised; call init_reweighting() first")
+        mcomps = np.abs(self._band_sum(x))
+        self.l1weight = (1 + self.rmsfactor) / (1 + mcomps**self.alpha / self._rms_comps[:, None, None] ** self.alpha)
 
     def dual_update(self, vp, v, lam, sigma=1.0):
         dual_update_numba_fast(vp, v, lam, sigma=sigma, weight=self.l1weight)

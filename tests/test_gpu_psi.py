@@ -216,3 +216,30 @@ def test_primal_dual_device_loop(layout, positivity, use_beam):
     assert pd2._device_path() is None
     got2 = pd2.solve(model.copy(), lam)
     assert rel(got2, xr) < 1e-7 and pd2.last["iters"] == kr
+
+
+def test_l21_reweighting():
+    """L21.init_reweighting / update_weights (prox/l21.py:56-88, utils/misc.py:742-755) on the GPU analysis."""
+    from pfb_imaging_amd.operators.psi import Psi
+    from pfb_imaging_amd.opt import L21
+
+    nband, nx, ny, bases = 2, 32, 48, ("self", "db2")
+    rng = np.random.default_rng(4)
+    psi = Psi(nband, nx, ny, bases, 2, 1)
+    reg = L21(psi, bases, rmsfactor=0.7, alpha=2.0)
+    assert not reg.reweight_active
+    with pytest.raises(RuntimeError):
+        reg.update_weights(np.zeros((nband, nx, ny)))
+    upd = rng.standard_normal((nband, nx, ny))
+    reg.init_reweighting(upd)
+    assert reg.reweight_active
+    o = opsi.Psi(nband, nx, ny, bases, 2, transposed=True)
+    a = np.zeros((nband, 2, o.nymax, o.nxmax))
+    o.dot(upd, a)
+    s = a.sum(axis=0)
+    rms = np.array([np.std(s[i][s[i] != 0]) for i in range(2)])
+    x = rng.standard_normal((nband, nx, ny))
+    reg.update_weights(x)
+    o.dot(x, a)
+    ref = 1.7 / (1 + np.abs(a.sum(axis=0)) ** 2 / rms[:, None, None] ** 2)
+    assert reg.l1weight.shape == ref.shape and rel(reg.l1weight, ref) < 1e-12
