@@ -21,11 +21,6 @@
 
 namespace pfbhip {
 
-__global__ void __launch_bounds__(256) k_pd_extrapolate(const double *__restrict__ v, double *__restrict__ vp, int64_t n)
-{
-    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
-    if (i < n) vp[i] = 2.0 * v[i] - vp[i];
-}
 __global__ void __launch_bounds__(256) k_pd_diff(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ d,
                                                  int64_t n)
 {
@@ -83,15 +78,16 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *pc, int64_t nband, const
             ~Restore() { (void)psi_swap_stream(p, prev); }
         } restore{psi, psi_swap_stream(psi, st)};
 
-        DevBuf<double> x(nimg), xp(nimg), xout(nimg), xt(nimg), d(npix), v(ncoef), vp(ncoef), w(cube), sum(cube);
+        // Buffer rotation instead of copies: xa / xb alternate as (x, xp); va / vb alternate as (dual, previous
+        // dual); vext holds the extrapolated dual 2 v - vp of the current iteration.
+        DevBuf<double> xa(nimg), xb(nimg), xout(nimg), xt(nimg), d(npix), va(ncoef), vb(ncoef), vext(ncoef), w(cube);
         DevBuf<double> partials(3 * size_t(CG_BLOCKS));
         std::vector<double> hpart(3 * size_t(CG_BLOCKS));
-        PFB_HIP(hipMemcpyAsync(x.p, x_host, nimg * sizeof(double), hipMemcpyHostToDevice, st));
+        double *xp = xa.p, *x = xb.p, *vp = va.p, *v = vb.p;
+        PFB_HIP(hipMemcpyAsync(xp, x_host, nimg * sizeof(double), hipMemcpyHostToDevice, st));
         PFB_HIP(hipMemcpyAsync(xt.p, xtilde_host, nimg * sizeof(double), hipMemcpyHostToDevice, st));
-        PFB_HIP(hipMemcpyAsync(v.p, v_host, ncoef * sizeof(double), hipMemcpyHostToDevice, st));
+        PFB_HIP(hipMemcpyAsync(vp, v_host, ncoef * sizeof(double), hipMemcpyHostToDevice, st));
         PFB_HIP(hipMemcpyAsync(w.p, weight_host, cube * sizeof(double), hipMemcpyHostToDevice, st));
-        PFB_HIP(hipMemcpyAsync(xp.p, x.p, nimg * sizeof(double), hipMemcpyDeviceToDevice, st));
-        PFB_HIP(hipMemcpyAsync(vp.p, v.p, ncoef * sizeof(double), hipMemcpyDeviceToDevice, st));
         std::vector<int64_t> off(size_t(nband) + 1, 0);
         for (int64_t b = 0; b < nband; ++b) {
             PFB_REQUIRE(nparts[b] >= 1, "band %lld has no partitions", (long long)b);
@@ -101,22 +97,21 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *pc, int64_t nband, const
         double eps = 1.0;
         int k = 0, status = 1;
         for (; k < maxit; ++k) {
-            for (int64_t b = 0; b < nband; ++b) psi_dot_async(psi, xp.p + size_t(b) * npix, v.p + size_t(b) * cube);
-            l21_vtilde_async(vp.p, v.p, nband, int64_t(cube), sigma, sum.p, st);
-            l21_scale_async(v.p, nband, int64_t(cube), lam, w.p, sum.p, st);
-            hipLaunchKernelGGL(k_pd_extrapolate, blocks(ncoef), dim3(256), 0, st, v.p, vp.p, int64_t(ncoef));
+            for (int64_t b = 0; b < nband; ++b) psi_dot_async(psi, xp + size_t(b) * npix, v + size_t(b) * cube);
+            // v <- dual update(vp, Psi^H xp) ; vext <- 2 v - vp   (one pass over the cubes)
+            l21_fused_async(vp, v, vext.p, nband, int64_t(cube), lam, sigma, w.p, st);
             for (int64_t b = 0; b < nband; ++b) {
                 double *xo = xout.p + size_t(b) * npix;
-                psi_hdot_async(psi, vp.p + size_t(b) * cube, xo);
-                hipLaunchKernelGGL(k_pd_diff, blocks(npix), dim3(256), 0, st, xt.p + size_t(b) * npix, xp.p + size_t(b) * npix, d.p,
+                psi_hdot_async(psi, vext.p + size_t(b) * cube, xo);
+                hipLaunchKernelGGL(k_pd_diff, blocks(npix), dim3(256), 0, st, xt.p + size_t(b) * npix, xp + size_t(b) * npix, d.p,
                                    int64_t(npix));
                 for (int64_t q = off[size_t(b)]; q < off[size_t(b) + 1]; ++q)
                     psfconv_apply_async(pc, d.p, psf_slots[q], beam_slots[q], 0, 0.0, -scale[b] / gamma,
                                         q == off[size_t(b)] ? -eta[b] / gamma : 0.0, 1, xo);
             }
-            hipLaunchKernelGGL(k_pd_primal, blocks(nimg), dim3(256), 0, st, x.p, xp.p, xout.p, tau, int64_t(nimg));
-            if (positivity) positivity_async(x.p, nband, int64_t(npix), positivity, st);
-            hipLaunchKernelGGL(k_pd_norms, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, st, int64_t(nimg), x.p, xp.p, partials.p);
+            hipLaunchKernelGGL(k_pd_primal, blocks(nimg), dim3(256), 0, st, x, xp, xout.p, tau, int64_t(nimg));
+            if (positivity) positivity_async(x, nband, int64_t(npix), positivity, st);
+            hipLaunchKernelGGL(k_pd_norms, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, st, int64_t(nimg), x, xp, partials.p);
             PFB_HIP(hipGetLastError());
             PFB_HIP(hipMemcpyAsync(hpart.data(), partials.p, hpart.size() * sizeof(double), hipMemcpyDeviceToHost, st));
             PFB_HIP(hipStreamSynchronize(st));
@@ -131,11 +126,16 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *pc, int64_t nband, const
                 status = 0;
                 break;
             }
-            PFB_HIP(hipMemcpyAsync(xp.p, x.p, nimg * sizeof(double), hipMemcpyDeviceToDevice, st));
-            PFB_HIP(hipMemcpyAsync(vp.p, v.p, ncoef * sizeof(double), hipMemcpyDeviceToDevice, st));
+            std::swap(x, xp);  // xp <- x
+            std::swap(v, vp);  // vp <- v
         }
-        PFB_HIP(hipMemcpyAsync(x_host, x.p, nimg * sizeof(double), hipMemcpyDeviceToHost, st));
-        PFB_HIP(hipMemcpyAsync(v_host, v.p, ncoef * sizeof(double), hipMemcpyDeviceToHost, st));
+        // after a break x / v hold the last iterate; after maxit the final swap moved them to xp / vp
+        if (status != 0) {
+            std::swap(x, xp);
+            std::swap(v, vp);
+        }
+        PFB_HIP(hipMemcpyAsync(x_host, x, nimg * sizeof(double), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipMemcpyAsync(v_host, v, ncoef * sizeof(double), hipMemcpyDeviceToHost, st));
         PFB_HIP(hipStreamSynchronize(st));
         if (info) {
             info->iters = status == 0 ? k : maxit - 1;  // the reference reports the loop index k

@@ -20,6 +20,9 @@ void psi_hdot_async(pfbhip_psi *p, const double *alpha_dev, double *x_dev);
 void l21_vtilde_async(const double *vp_dev, double *v_dev, int64_t nband, int64_t n, double sigma, double *sum_dev, hipStream_t st);
 void l21_scale_async(double *v_dev, int64_t nband, int64_t n, double lam, const double *weight_dev, const double *sum_dev,
                      hipStream_t st);
+// a = Psi^H xp in; a = updated dual, ext = 2 a - vp out (all bands on this device)
+void l21_fused_async(const double *vp_dev, double *a_dev, double *ext_dev, int64_t nband, int64_t n, double lam, double sigma,
+                     const double *weight_dev, hipStream_t st);
 void positivity_async(double *x_dev, int64_t nband, int64_t n, int mode, hipStream_t st);
 
 // PSF convolution (psfconv.hip)

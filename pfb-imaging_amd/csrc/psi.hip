@@ -184,6 +184,27 @@ __global__ void __launch_bounds__(256) k_l21_scale(double *__restrict__ v, int n
         for (int b = 0; b < nband; ++b) v[size_t(b) * size_t(n) + size_t(i)] *= sc;
     }
 }
+// all bands local: both phases and the dual extrapolation in ONE pass over the cubes.
+// a = Psi^H xp on entry; on exit a = v_new (the updated dual) and ext = 2 v_new - vp.
+__global__ void __launch_bounds__(256) k_l21_fused(const double *__restrict__ vp, double *__restrict__ a, double *__restrict__ ext,
+                                                    int nband, int64_t n, double lam, double sigma,
+                                                    const double *__restrict__ weight)
+{
+    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nband; ++b) s += vp[size_t(b) * size_t(n) + size_t(i)] + sigma * a[size_t(b) * size_t(n) + size_t(i)];
+    const double as = fabs(s), thr = lam * weight[i];
+    const double sc = as > thr ? thr / as : 1.0;
+    for (int b = 0; b < nband; ++b) {
+        const size_t o = size_t(b) * size_t(n) + size_t(i);
+        const double p = vp[o];
+        const double vn = (p + sigma * a[o]) * sc;
+        a[o] = vn;
+        ext[o] = 2.0 * vn - p;
+    }
+}
+
 // prox_{sigma ||.||_21}(v): v * max(|s| - sigma w, 0) / |s|, s = band sum (prox_21m.py:5-26)
 __global__ void __launch_bounds__(256) k_prox21(const double *__restrict__ v, int nband, int64_t n, double sigma,
                                                 const double *__restrict__ weight, double *__restrict__ out)
@@ -338,6 +359,13 @@ void l21_scale_async(double *v_dev, int64_t nband, int64_t n, double lam, const 
 {
     hipLaunchKernelGGL(k_l21_scale, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, st, v_dev, int(nband), n, lam, weight_dev,
                        sum_dev);
+    PFB_HIP(hipGetLastError());
+}
+void l21_fused_async(const double *vp_dev, double *a_dev, double *ext_dev, int64_t nband, int64_t n, double lam, double sigma,
+                     const double *weight_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_l21_fused, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, st, vp_dev, a_dev, ext_dev, int(nband), n, lam,
+                       sigma, weight_dev);
     PFB_HIP(hipGetLastError());
 }
 void positivity_async(double *x_dev, int64_t nband, int64_t n, int mode, hipStream_t st)
