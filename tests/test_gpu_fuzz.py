@@ -63,3 +63,45 @@ def test_fuzz_vs_dft(k):
     if np.linalg.norm(refh) > 0:
         assert rel(h, refh) < 2 * p["eps"], (p, g.info)
     g.close()
+
+
+def test_edge_cases_row_fft_paths():
+    """Degenerate inputs on the paths that take the hand-written row FFT (grid >= 1024): no unmasked
+    visibility, a single visibility, PSF convolution without padding and with a 2-row image."""
+    from pfb_imaging_amd.psfconv import PsfConv
+    from pfb_imaging_amd.wgridder import Gridder
+
+    rng = np.random.default_rng(0)
+    c = synth.make_case(40, 2, 1024, zscale=0.01, seed=2)
+    kw = dict(npix_x=1024, npix_y=1024, pixsize_x=c["cell"], pixsize_y=c["cell"], epsilon=1e-6, flip_v=True,
+              do_wgridding=True, divide_by_n=False)
+    g = Gridder(c["uvw"], c["freq"], np.zeros_like(c["mask"]), **kw)  # everything masked
+    assert g.info["nactive"] == 0
+    assert not g.vis2dirty(c["vis"], c["wgt"]).any()
+    assert not g.dirty2vis(c["x"]).any()
+    g.close()
+    one = np.zeros_like(c["mask"])
+    one[7, 1] = 1
+    g = Gridder(c["uvw"], c["freq"], one, **kw)  # a single visibility
+    assert g.info["nactive"] == 1 and g.info["fft_mode"] == 3
+    d = g.vis2dirty(c["vis"], c["wgt"])
+    from oracle import dft
+
+    ref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], one, 1024, 1024, c["cell"], c["cell"], 0.0, 0.0, False,
+                            True, False, True, False)
+    assert np.linalg.norm(d - ref) / np.linalg.norm(ref) < 1e-6
+    v = g.dirty2vis(c["x"])
+    assert np.count_nonzero(v) == 1
+    g.close()
+    # PSF convolution: no padding at all (circular convolution), and a 2-row image in a padded plan
+    for nx, ny, nxp, nyp in ((1024, 1024, 1024, 1024), (2, 700, 1024, 2048)):
+        psfhat = np.fft.rfft2(rng.standard_normal((nxp, nyp)))
+        x = rng.standard_normal((nx, ny))
+        pc = PsfConv(nx, ny, nxp, nyp)
+        pc.set_psfhat(0, psfhat)
+        got = pc.apply(x, 0)
+        xp = np.zeros((nxp, nyp))
+        xp[:nx, :ny] = x
+        want = np.fft.irfft2(np.fft.rfft2(xp) * psfhat, s=(nxp, nyp))[:nx, :ny]
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-12
+        pc.close()
