@@ -282,8 +282,8 @@ int pfbhip_positivity_dev(double *x_dev, int64_t nband, int64_t n, int mode);
 /* Primal-dual backward step with every cube resident on the device: PrimalDual.solve
  * (src/pfb_imaging/opt/primal_dual.py:406-448) with the l21 regulariser over `psi` (prox/l21.py:15-50) and
  * grad(x) = -H (xtilde - x) / gamma (deconv/pfb.py:158-161), H_b(x) = scale[b] sum_p beam_p (PSF_p * (beam_p x)) +
- * eta[b] x from the slots of `pc` (band b owns nparts[b] consecutive entries of psf_slots / beam_slots, as
- * in pfbhip_psfconv_cg).  x (nband, nx, ny): initial iterate in, solution out; v (nband, nbasis, nxmax, nymax):
+ * eta[b] x from the slots of band b's plan pcs[b] (one plan for all bands -- HessPSF -- or one per band --
+ * HessTreeRay; band b owns nparts[b] consecutive entries of psf_slots / beam_slots, as in pfbhip_psfconv_cg).  x (nband, nx, ny): initial iterate in, solution out; v (nband, nbasis, nxmax, nymax):
  * warm-started dual in / out; weight (nbasis, nxmax, nymax); positivity 0 | 1 | 2 (prox/positivity.py).
  * Stops when ||x - xp|| / ||x|| < tol or after maxit iterations; info->iters is the last loop index. */
 typedef struct pfbhip_pd_info {
@@ -291,7 +291,7 @@ typedef struct pfbhip_pd_info {
     int32_t status; /* 0 converged, 1 maxit reached */
     double eps;
 } pfbhip_pd_info;
-int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *pc, int64_t nband, const int64_t *nparts, const int64_t *psf_slots,
+int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs /* [nband] */, int64_t nband, const int64_t *nparts, const int64_t *psf_slots,
                        const int64_t *beam_slots, const double *scale, const double *eta, const double *xtilde_host, double gamma,
                        double *x_host, double *v_host, const double *weight_host, double lam, double sigma, double tau,
                        int positivity, double tol, int maxit, pfbhip_pd_info *info);

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -52,13 +53,13 @@ using namespace pfbhip;
 
 extern "C" {
 
-int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *pc, int64_t nband, const int64_t *nparts, const int64_t *psf_slots,
+int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nband, const int64_t *nparts, const int64_t *psf_slots,
                        const int64_t *beam_slots, const double *scale, const double *eta, const double *xtilde_host, double gamma,
                        double *x_host, double *v_host, const double *weight_host, double lam, double sigma, double tau,
                        int positivity, double tol, int maxit, pfbhip_pd_info *info)
 {
     return guarded([&] {
-        PFB_REQUIRE(psi && pc && nparts && psf_slots && beam_slots && scale && eta && xtilde_host && x_host && v_host &&
+        PFB_REQUIRE(psi && pcs && nparts && psf_slots && beam_slots && scale && eta && xtilde_host && x_host && v_host &&
                         weight_host && nband >= 1 && maxit >= 1,
                     "bad arguments");
         PFB_REQUIRE(positivity >= 0 && positivity <= 2, "positivity mode %d", positivity);
@@ -66,17 +67,36 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *pc, int64_t nband, const
         int64_t nx, ny, nxmax, nymax, px, py;
         int nbasis;
         psi_geometry(psi, &nx, &ny, &nbasis, &nxmax, &nymax);
-        psfconv_geometry(pc, &px, &py);
-        PFB_REQUIRE(px == nx && py == ny, "Psi is (%lld, %lld) but the PSF plan is (%lld, %lld)", (long long)nx, (long long)ny,
-                    (long long)px, (long long)py);
+        for (int64_t b = 0; b < nband; ++b) {
+            PFB_REQUIRE(pcs[b] != nullptr, "band %lld has no PSF plan", (long long)b);
+            psfconv_geometry(pcs[b], &px, &py);
+            PFB_REQUIRE(px == nx && py == ny, "Psi is (%lld, %lld) but the PSF plan of band %lld is (%lld, %lld)", (long long)nx,
+                        (long long)ny, (long long)b, (long long)px, (long long)py);
+        }
         const size_t npix = size_t(nx) * size_t(ny), cube = size_t(nbasis) * size_t(nxmax) * size_t(nymax);
         const size_t nimg = size_t(nband) * npix, ncoef = size_t(nband) * cube;
-        hipStream_t st = psfconv_stream(pc);
+        // one stream for everything: the first plan's; Psi and the other plans are switched to it for the call
+        hipStream_t st = psfconv_stream(pcs[0]);
         struct Restore {
             pfbhip_psi *p;
             hipStream_t prev;
-            ~Restore() { (void)psi_swap_stream(p, prev); }
-        } restore{psi, psi_swap_stream(psi, st)};
+            std::vector<std::pair<pfbhip_psfconv *, hipStream_t>> plans;
+            ~Restore()
+            {
+                (void)psi_swap_stream(p, prev);
+                for (auto it = plans.rbegin(); it != plans.rend(); ++it) {
+                    try {
+                        (void)psfconv_swap_stream(it->first, it->second);
+                    } catch (...) {
+                    }
+                }
+            }
+        } restore{psi, psi_swap_stream(psi, st), {}};
+        for (int64_t b = 1; b < nband; ++b) {
+            bool seen = pcs[b] == pcs[0];
+            for (auto &pr : restore.plans) seen = seen || pr.first == pcs[b];
+            if (!seen) restore.plans.emplace_back(pcs[b], psfconv_swap_stream(pcs[b], st));
+        }
 
         // Buffer rotation instead of copies: xa / xb alternate as (x, xp); va / vb alternate as (dual, previous
         // dual); vext holds the extrapolated dual 2 v - vp of the current iteration.
@@ -106,7 +126,7 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *pc, int64_t nband, const
                 hipLaunchKernelGGL(k_pd_diff, blocks(npix), dim3(256), 0, st, xt.p + size_t(b) * npix, xp + size_t(b) * npix, d.p,
                                    int64_t(npix));
                 for (int64_t q = off[size_t(b)]; q < off[size_t(b) + 1]; ++q)
-                    psfconv_apply_async(pc, d.p, psf_slots[q], beam_slots[q], 0, 0.0, -scale[b] / gamma,
+                    psfconv_apply_async(pcs[b], d.p, psf_slots[q], beam_slots[q], 0, 0.0, -scale[b] / gamma,
                                         q == off[size_t(b)] ? -eta[b] / gamma : 0.0, 1, xo);
             }
             hipLaunchKernelGGL(k_pd_primal, blocks(nimg), dim3(256), 0, st, x, xp, xout.p, tau, int64_t(nimg));

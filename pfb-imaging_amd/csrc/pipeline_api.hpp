@@ -27,6 +27,8 @@ void positivity_async(double *x_dev, int64_t nband, int64_t n, int mode, hipStre
 
 // PSF convolution (psfconv.hip)
 hipStream_t psfconv_stream(pfbhip_psfconv *p);
+// all launches of the plan go to `st` until swapped back; returns the previous stream
+hipStream_t psfconv_swap_stream(pfbhip_psfconv *p, hipStream_t st);
 void psfconv_geometry(const pfbhip_psfconv *p, int64_t *nx, int64_t *ny);
 void psfconv_apply_async(pfbhip_psfconv *p, const double *x_dev, int64_t psf_slot, int64_t beam_slot, int mode, double shift,
                          double scale, double eta, int accumulate, double *out_dev);

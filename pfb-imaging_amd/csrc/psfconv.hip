@@ -206,6 +206,14 @@ struct pfbhip_psfconv {
 
 namespace pfbhip {
 hipStream_t psfconv_stream(pfbhip_psfconv *p) { return p->stream; }
+hipStream_t psfconv_swap_stream(pfbhip_psfconv *p, hipStream_t st)
+{
+    hipStream_t prev = p->stream;
+    p->stream = st;
+    p->fft.stream = st;
+    if (p->fft.info) PFB_ROCFFT(rocfft_execution_info_set_stream(p->fft.info, st));
+    return prev;
+}
 void psfconv_geometry(const pfbhip_psfconv *p, int64_t *nx, int64_t *ny)
 {
     *nx = p->nx;

@@ -122,34 +122,58 @@ class PrimalDual:
             self._v[...] = 0.0
 
     # ---- device-resident loop --------------------------------------------------------------
+    @staticmethod
+    def _hess_bands(hess, nband):
+        """Per band: (plan handle owner, psf slots, beam slots, scale, eta) of a device-resident PSF Hessian, or
+        None if ``hess`` is not one this process holds completely (HessPSF; HessTreeRay over a local pool)."""
+        from .operators.hessian import HessPSF, HessTreeRay
+
+        if isinstance(hess, HessPSF) and hess.nband == nband:
+            return [(hess._plan, [b], [-1 if hess.beam[b] is None else b], 1.0, float(hess.eta[b])) for b in range(nband)]
+        if isinstance(hess, HessTreeRay) and hess.nband == nband:
+            pool = hess._pool
+            if pool.comm is not None and pool.comm.world_size > 1:
+                return None  # bands live on other ranks: the generic loop runs them through the pool
+            out = []
+            for b in range(nband):
+                tree = getattr(pool.workers[b], "_hess", None)
+                if tree is None or tree.ncorr != 1:
+                    return None
+                s = tree._slots(0)
+                out.append((tree._plan, s, s, 1.0 / float(tree.wsum[0]), float(tree.eta)))
+            return out
+        return None
+
     def _device_path(self):
-        from .operators.hessian import HessPSF
         from .prox import positivity, positivity_band
 
         g, reg = self._grad, self._reg
-        if not (isinstance(g, PsfGrad) and isinstance(g.hess, HessPSF) and isinstance(reg, L21)):
+        if not (isinstance(g, PsfGrad) and isinstance(reg, L21)) or self.on_converge is not None:
             return None
-        if not isinstance(reg.psi, (Psi, PsiNocopyt)) or self.on_converge is not None:
+        if not isinstance(reg.psi, (Psi, PsiNocopyt)):
             return None
-        mode = {None: 0, positivity: 1, positivity_band: 2}.get(self.primal_prox, None)
-        return mode
+        if self._hess_bands(g.hess, reg.psi.nband) is None:
+            return None
+        return {None: 0, positivity: 1, positivity_band: 2}.get(self.primal_prox, None)
 
     def _solve_device(self, x, lam, mode):
-        hess, reg, psi = self._grad.hess, self._reg, self._reg.psi
+        reg, psi = self._reg, self._reg.psi
         nband = psi.nband
+        bands = self._hess_bands(self._grad.hess, nband)
         transposed = isinstance(psi, Psi)
         v = self._v.transpose(0, 1, 3, 2) if transposed else self._v
-        w = reg.l1weight.T if False else (reg.l1weight.transpose(0, 2, 1) if transposed else reg.l1weight)
+        w = reg.l1weight.transpose(0, 2, 1) if transposed else reg.l1weight
         v = np.ascontiguousarray(v, dtype=np.float64)
         w = np.ascontiguousarray(np.broadcast_to(w, v.shape[1:]), dtype=np.float64)
         xs = np.ascontiguousarray(x, dtype=np.float64).copy()
-        nparts = np.ones(nband, dtype=np.int64)
-        psf_slots = np.arange(nband, dtype=np.int64)
-        beam_slots = np.array([-1 if hess.beam[b] is None else b for b in range(nband)], dtype=np.int64)
-        scale = np.ones(nband)
-        eta = np.ascontiguousarray(hess.eta, dtype=np.float64)
+        handles = (ct.c_void_p * nband)(*[b[0]._h for b in bands])
+        nparts = np.array([len(b[1]) for b in bands], dtype=np.int64)
+        psf_slots = np.array([s for b in bands for s in b[1]], dtype=np.int64)
+        beam_slots = np.array([s for b in bands for s in b[2]], dtype=np.int64)
+        scale = np.array([b[3] for b in bands], dtype=np.float64)
+        eta = np.array([b[4] for b in bands], dtype=np.float64)
         info = PDInfo()
-        check(lib().pfbhip_primal_dual(psi._band._h, hess._plan._h, i64(nband), ptr(nparts), ptr(psf_slots), ptr(beam_slots),
+        check(lib().pfbhip_primal_dual(psi._band._h, handles, i64(nband), ptr(nparts), ptr(psf_slots), ptr(beam_slots),
                                        ptr(scale), ptr(eta), ptr(self._grad.xtilde), f64(self._grad.gamma), ptr(xs), ptr(v),
                                        ptr(w), f64(lam), f64(self.sigma), f64(self.tau), cint(mode), f64(self.tol),
                                        cint(self.maxit), ct.byref(info)))

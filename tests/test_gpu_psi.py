@@ -243,3 +243,43 @@ def test_l21_reweighting():
     o.dot(x, a)
     ref = 1.7 / (1 + np.abs(a.sum(axis=0)) ** 2 / rms[:, None, None] ** 2)
     assert reg.l1weight.shape == ref.shape and rel(reg.l1weight, ref) < 1e-12
+
+
+def test_primal_dual_device_loop_hess_tree_ray():
+    """The presets.py composition (deconv/presets.py:100-130): PsiNocopyt-layout dictionary + HessTreeRay (one PSF
+    plan per band, two partitions each) runs the device loop too and matches the generic loop."""
+    from pfb_imaging_amd import prox
+    from pfb_imaging_amd.operators.hessian import HessTreeRay
+    from pfb_imaging_amd.operators.psi import PsiNocopyt
+    from pfb_imaging_amd.opt import L21, PrimalDual, PsfGrad
+
+    nband, nx, ny, nxp, nyp = 2, 32, 48, 64, 96
+    bases = ("self", "db1", "db3")
+    rng = np.random.default_rng(5)
+    parts = []
+    for b in range(nband):
+        pb = []
+        for _ in range(2):
+            psf = np.zeros((1, nxp, nyp))
+            psf[:, 0, 0] = 1.0
+            psf += 0.02 * rng.standard_normal(psf.shape)
+            pb.append({"psfhat": np.abs(np.fft.rfft2(psf, axes=(1, 2))), "beam": 0.8 + 0.2 * rng.random((1, nx, ny)),
+                       "wsum": np.array([1.0 + rng.random()])})
+        parts.append(pb)
+    hess = HessTreeRay(parts, nx, ny, nxp, nyp, etas=[0.05, 0.1])
+    psi = PsiNocopyt(nband, nx, ny, bases, 2, 1)
+    reg = L21(psi, bases, nu=np.sqrt(len(bases)))
+    reg.l1weight = 0.5 + rng.random(reg.l1weight.shape)
+    model = np.abs(rng.standard_normal((nband, nx, ny))) * (rng.random((nband, nx, ny)) > 0.8)
+    xtilde = model + 0.3 * rng.standard_normal(model.shape)
+    hessnorm = 1.4
+    res = {}
+    for name in ("device", "generic"):
+        pd = PrimalDual(tol=1e-7, maxit=30, verbosity=0, gamma=1.0, primal_prox=prox.positivity_band)
+        pd.setup(reg, hessnorm)
+        g = PsfGrad(hess, xtilde, 1.0)
+        pd.set_grad(g if name == "device" else (lambda z: g(z)))
+        assert (pd._device_path() == 2) == (name == "device")
+        res[name] = (pd.solve(model.copy(), 0.02), pd.last["iters"])
+    assert res["device"][1] == res["generic"][1]
+    assert rel(res["device"][0], res["generic"][0]) < 1e-9
