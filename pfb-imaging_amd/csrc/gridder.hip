@@ -913,8 +913,10 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
                 //  streaming passes at 5 TB/s;
                 //  scatter + gather: 0.30 ns per visibility and touched plane, independent of W <= 16 (the
                 //  diagonal walk always takes 16 steps of LDS atomics / reads).
+                // (x 1.2 on the rocFFT path: its measured table is for the large sizes only, and every distinct size
+                // costs 1-3 s of rocFFT plan building that the hand-written path does not have)
                 const double plane_cost = own ? 2.7e-11 * double(nu) * double(nv)
-                                              : fft2d_seconds(nu, nv) + 3.0 * 16.0 * double(nu) * double(nv) / 5.0e12;
+                                              : 1.2 * (fft2d_seconds(nu, nv) + 3.0 * 16.0 * double(nu) * double(nv) / 5.0e12);
                 const double gridcost = nvis * double(std::min<int64_t>(touched, npl)) * 0.30e-9;
                 const double cost = double(npl) * plane_cost + gridcost;
                 // cheapest wins; within 1 % the more accurate row does (W is free up to 16, so the best row

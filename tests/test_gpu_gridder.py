@@ -400,3 +400,26 @@ def test_own_fft_shapes_vs_oracle(nx, ny, center, widen, zscale):
     refv[mask[rows] == 0] = 0
     assert rel(v[rows], refv) < kw["epsilon"]
     g.close()
+
+
+@pytest.mark.parametrize("eps", [1e-4, 1e-10])
+def test_epsilon_contract_own_fft_path(eps):
+    """Accuracy contract at both ends of the range on a grid the hand-written FFT path serves (>= 1024)."""
+    c = make(nrow=1200, npix=64, widen=10.0, zscale=0.1)
+    rng = np.random.default_rng(9)
+    c["nx"] = c["ny"] = 900
+    c["cell"] = c["cell"] * 64.0 / 900
+    c["x"] = rng.standard_normal((900, 900))
+    g, kw, mask = gpu_plan(c, epsilon=eps)
+    assert g.info["fft_mode"] == 3, g.info
+    rows = slice(0, 150)
+    v = g.dirty2vis(c["x"])
+    refv = dft.dft_dirty2vis(c["uvw"][rows], c["freq"], c["x"], c["cell"], c["cell"], 0.0, 0.0, False, True, False, True, False)
+    refv[mask[rows] == 0] = 0
+    assert rel(v[rows], refv) < eps
+    # adjointness ties vis2dirty to the same accuracy
+    y = c["vis"] * mask
+    lhs = np.vdot(v, y).real
+    rhs = np.vdot(c["x"], g.vis2dirty(y))
+    assert abs(lhs - rhs) <= 1e-9 * abs(rhs)
+    g.close()
