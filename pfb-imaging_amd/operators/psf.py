@@ -6,7 +6,6 @@ Same signatures and in-place contract as /root/reference/src/pfb_imaging/operato
 left untouched).  ``psfhat`` may be complex or real; an identical array is uploaded once.
 """
 
-import numpy as np
 
 from ..psfconv import cached_plan, cached_psf_slot
 

@@ -14,7 +14,7 @@ import ctypes as ct
 import numpy as np
 
 from . import _lib
-from ._lib import PDInfo, as_c, check, cint, f64, i64, lib, ptr
+from ._lib import PDInfo, check, cint, f64, i64, lib, ptr
 from .operators.psi import Psi, PsiNocopyt
 from .prox import dual_update_numba_fast, prox_21m_numba
 

@@ -18,7 +18,7 @@ import zlib
 import numpy as np
 
 from . import _lib
-from ._lib import CGInfo, DeviceArray, GridderInfo, GridderParams, as_c, check, cint, f64, i64, lib, ptr
+from ._lib import CGInfo, GridderInfo, GridderParams, as_c, check, cint, f64, i64, lib, ptr
 
 
 class Gridder:

@@ -9,7 +9,6 @@ quantities are comparable).  Tolerances:
                                     the reference's gridder (ducc0)
 """
 
-import itertools
 
 import numpy as np
 import pytest
