@@ -231,7 +231,7 @@ __global__ void k_scale_sorted(int64_t nactive, const double2 *in, const double 
     out[j] = v;
 }
 
-// correction image: cfu[ix] cfv[iy] / psi_w(t dw) [/ n]
+// correction image: cfu[ix] cfv[iy] / psi_w(t dw) [/ n], in the layout of the accumulator accT (ny, nx)
 __global__ void k_corr_image(ImgGeom g, const double *cfu, const double *cfv, const double *cheb, int ncheb, double dw,
                              double zmax, int do_w, int use_psiw, int divide_by_n, double *corr)
 {
@@ -255,7 +255,7 @@ __global__ void k_corr_image(ImgGeom g, const double *cfu, const double *cfv, co
         }
         if (divide_by_n) c /= (t - g.nshift + 1.0);
     }
-    corr[p] = c;
+    corr[size_t(iy) * size_t(g.nx) + size_t(ix)] = c;  // stored transposed: (ny, nx) like the image accumulator
 }
 
 // ---------------------------------------------------------------------------------------
@@ -277,50 +277,29 @@ __global__ void k_corr_image(ImgGeom g, const double *cfu, const double *cfv, co
 
 constexpr int TP = 32;  // transpose tile
 
-// out (nc, nr) = in (nr, nc)^T [* mul (nr, nc)] [* mul2]   (real images)
-__global__ void k_transpose_f64(const double *in, const double *mul, const double *mul2, int nr, int nc, double *out)
+// The plan works on the TRANSPOSED problem (pfbhip_gridder_create exchanges the two image axes, u <-> v), so its
+// transposed accumulator accT (ny, nx) IS the caller's image layout: the image-side steps are element-wise.
+// accT = x * corr [* beam]   (degrid input)
+__global__ void __launch_bounds__(256) k_prepare_img(const double *x, const double *corr, const double *beam, int64_t n,
+                                                      double *out)
 {
-    __shared__ double t[TP][TP + 1];
-    int c0 = blockIdx.x * TP, r0 = blockIdx.y * TP;
-    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
-        int r = r0 + k, c = c0 + threadIdx.x;
-        if (r < nr && c < nc) {
-            size_t o = size_t(r) * nc + c;
-            double v = in[o];
-            if (mul) v *= mul[o];
-            if (mul2) v *= mul2[o];
-            t[k][threadIdx.x] = v;
-        }
-    }
-    __syncthreads();
-    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
-        int c = c0 + k, r = r0 + threadIdx.x;
-        if (r < nr && c < nc) out[size_t(c) * nr + r] = t[threadIdx.x][k];
-    }
+    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (i >= n) return;
+    double v = x[i] * corr[i];
+    if (beam) v *= beam[i];
+    out[i] = v;
 }
-
-// out (nx, ny) = accT (ny, nx)^T * corr [* beam] * scale + eta * x     (finalize with transposed accumulator)
-__global__ void k_finalize_T(const double *accT, const double *corr, const double *beam, double scale, double eta,
-                             const double *x, int nx, int ny, double *out)
+// out = accT * corr [* beam] * scale + eta * x
+__global__ void __launch_bounds__(256) k_finalize_img(const double *accT, const double *corr, const double *beam, double scale,
+                                                       double eta, const double *x, int64_t n, double *out)
 {
-    __shared__ double t[TP][TP + 1];
-    int x0 = blockIdx.x * TP, y0 = blockIdx.y * TP;  // accT row = y, col = x
-    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
-        int y = y0 + k, xx = x0 + threadIdx.x;
-        if (y < ny && xx < nx) t[k][threadIdx.x] = accT[size_t(y) * nx + xx];
-    }
-    __syncthreads();
-    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
-        int xx = x0 + k, y = y0 + threadIdx.x;
-        if (y < ny && xx < nx) {
-            size_t o = size_t(xx) * ny + y;
-            double v = t[threadIdx.x][k] * corr[o];
-            if (beam) v *= beam[o];
-            v *= scale;
-            if (x) v += eta * x[o];
-            out[o] = v;
-        }
-    }
+    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (i >= n) return;
+    double v = accT[i] * corr[i];
+    if (beam) v *= beam[i];
+    v *= scale;
+    if (x) v += eta * x[i];
+    out[i] = v;
 }
 
 // B (ny, nu) <- A (nu, nv): B[y][u] = A[u][wrap(y - ny/2, nv)] for occupied 32-row blocks of u, 0 elsewhere
@@ -487,7 +466,8 @@ struct StageTimer {
 using namespace pfbhip;
 
 struct pfbhip_gridder {
-    pfbhip_gridder_params prm{};
+    pfbhip_gridder_params prm{};   // the TRANSPOSED problem the plan works on (image axes, pixel sizes, centres and u/v flips exchanged)
+    pfbhip_gridder_params uprm{};  // the caller's parameters
     pfbhip_gridder_info info{};
     int device = 0;
     hipStream_t stream = nullptr;
@@ -688,13 +668,15 @@ struct pfbhip_gridder {
     dim3 tgrid(int64_t ncols, int64_t nrows) const { return dim3(uint32_t(ceil_div(ncols, TP)), uint32_t(ceil_div(nrows, TP))); }
 
     // sval (tile-sorted, weighted) -> accT, the TRANSPOSED (ny, nx) raw image (before correction)
-    void grid_all_planes(const double2 *sval)
+    // `fin` (fused path only): the last launch writes the finalized image; returns true if it did
+    bool grid_all_planes(const double2 *sval, const FusedFinal *fin = nullptr)
     {
         const int64_t npix = int64_t(prm.nx) * prm.ny;
         if (info.nactive == 0 || info.nwork == 0) {
             PFB_HIP(hipMemsetAsync(d_accT.p, 0, npix * sizeof(double), stream));
-            return;
+            return false;
         }
+        bool finalized = false;
         for (int p0 = 0; p0 < info.nplanes; p0 += kp_max) {
             const int kp = int(std::min<int64_t>(kp_max, info.nplanes - p0));
             timer.begin(5);
@@ -728,11 +710,27 @@ struct pfbhip_gridder {
             }
             if (fused) {
                 timer.begin(6);
+                const bool last_group = p0 + kp >= info.nplanes;
+                FusedFinal f = (fin != nullptr && last_group) ? *fin : FusedFinal{};
+                if (f.corr != nullptr) finalized = true;
                 fused_fft_crop(rowfft_u, fused_geom(), d_occ.p, d_gridB.p, bstride, fused_planes(p0, kp), prm.do_wgridding,
-                               p0 == 0, d_accT.p, stream);
+                               p0 == 0, d_accT.p, f, stream);
                 timer.end();
             }
         }
+        return finalized;
+    }
+    // grid + finalize, folding the finalize into the last fused launch where possible
+    void grid_and_finalize(const double2 *sval, const double *beam, double scale, double eta, const double *x, double *out)
+    {
+        FusedFinal f;
+        f.corr = d_corr.p;
+        f.beam = beam;
+        f.x = x;
+        f.scale = scale;
+        f.eta = eta;
+        f.out = out;
+        if (!grid_all_planes(sval, fused ? &f : nullptr)) finalize(beam, scale, eta, x, out);
     }
 
     FusedGeom fgeom;  // filled once by create_impl (fused path)
@@ -745,28 +743,46 @@ struct pfbhip_gridder {
         return fp;
     }
 
-    // out = accT^T * corr [* beam] * scale + eta * x
+    // out = accT * corr [* beam] * scale + eta * x   (all in the caller's image layout)
     void finalize(const double *beam, double scale, double eta, const double *x, double *out)
     {
+        const int64_t npix = int64_t(prm.nx) * prm.ny;
         timer.begin(5);
-        hipLaunchKernelGGL(k_finalize_T, tgrid(prm.nx, prm.ny), dim3(TP, 8), 0, stream, d_accT.p, d_corr.p, beam, scale,
-                           eta, x, int(prm.nx), int(prm.ny), out);
+        hipLaunchKernelGGL(k_finalize_img, dim3(uint32_t(ceil_div(npix, 256))), dim3(256), 0, stream, d_accT.p, d_corr.p, beam, scale,
+                           eta, x, npix, out);
         PFB_HIP(hipGetLastError());
         timer.end();
     }
 
-    // accT = (x * corr [* beam])^T : the degrid input in the transposed layout
+    // accT = x * corr [* beam] : the degrid input
     void prepare_degrid_input(const double *x, const double *beam)
     {
+        const int64_t npix = int64_t(prm.nx) * prm.ny;
         timer.begin(5);
-        hipLaunchKernelGGL(k_transpose_f64, tgrid(prm.ny, prm.nx), dim3(TP, 8), 0, stream, x, d_corr.p, beam, int(prm.nx),
-                           int(prm.ny), d_accT.p);
+        hipLaunchKernelGGL(k_prepare_img, dim3(uint32_t(ceil_div(npix, 256))), dim3(256), 0, stream, x, d_corr.p, beam, npix,
+                           d_accT.p);
         PFB_HIP(hipGetLastError());
         timer.end();
+    }
+
+    // x -> sacc, folding the x * corr * beam step into the fused pad kernel where possible
+    void prepare_and_degrid(const double *x, const double *beam, double2 *sacc)
+    {
+        if (fused && info.nactive != 0 && info.nwork != 0) {
+            FusedPrep p;
+            p.x = x;
+            p.corr = d_corr.p;
+            p.beam = beam;
+            degrid_all_planes(sacc, &p);
+        } else {
+            prepare_degrid_input(x, beam);
+            degrid_all_planes(sacc);
+        }
     }
 
     // accT (transposed, corrected image) -> sacc (tile-sorted)
-    void degrid_all_planes(double2 *sacc)
+    // `prep` (fused path only): the fused pad kernel reads x * corr [* beam] itself instead of a prepared accT
+    void degrid_all_planes(double2 *sacc, const FusedPrep *prep = nullptr)
     {
         PFB_HIP(hipMemsetAsync(sacc, 0, size_t(std::max<int64_t>(info.nactive, 1)) * sizeof(double2), stream));
         if (info.nactive == 0 || info.nwork == 0) return;
@@ -774,8 +790,8 @@ struct pfbhip_gridder {
             const int kp = int(std::min<int64_t>(kp_max, info.nplanes - p0));
             if (fused) {
                 timer.begin(7);
-                fused_pad_fft(rowfft_u, fused_geom(), d_occ.p, d_accT.p, fused_planes(p0, kp), prm.do_wgridding, d_gridB.p,
-                              bstride, stream);
+                fused_pad_fft(rowfft_u, fused_geom(), d_occ.p, d_accT.p, prep != nullptr ? *prep : FusedPrep{},
+                              fused_planes(p0, kp), prm.do_wgridding, d_gridB.p, bstride, stream);
                 timer.end();
             }
             for (int k = 0; k < kp; ++k) {
@@ -1049,6 +1065,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     m.px = prm.pixsize_x;
     m.py = prm.pixsize_y;
     m.do_w = prm.do_wgridding;
+    m.swap_uv = 1;
 
     // w range over unmasked visibilities
     double wlo = 0.0, whi = 0.0;
@@ -1328,7 +1345,14 @@ int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw
     return guarded([&] {
         PFB_REQUIRE(params && out, "NULL argument");
         std::unique_ptr<pfbhip_gridder> g(new pfbhip_gridder);
+        // The plan runs the transposed problem: with u <-> v exchanged the pipeline's transposed accumulator
+        // (ny', nx') is the caller's (nx, ny) layout, so no image transposes are needed on either side.
+        g->uprm = *params;
         g->prm = *params;
+        std::swap(g->prm.nx, g->prm.ny);
+        std::swap(g->prm.pixsize_x, g->prm.pixsize_y);
+        std::swap(g->prm.center_x, g->prm.center_y);
+        std::swap(g->prm.flip_u, g->prm.flip_v);
         create_impl(g.get(), uvw_host, freq_host, mask_host);
         *out = g.release();
     });
@@ -1344,6 +1368,8 @@ int pfbhip_gridder_get_info(const pfbhip_gridder *g, pfbhip_gridder_info *info)
     return guarded([&] {
         PFB_REQUIRE(g && info, "NULL argument");
         *info = g->info;
+        std::swap(info->nu, info->nv);          // report the caller's orientation (the plan holds the transposed problem)
+        std::swap(info->lshift, info->mshift);
         info->device_bytes = g->device_bytes();
     });
 }
@@ -1367,8 +1393,9 @@ int pfbhip_gridder_get_binmap(pfbhip_gridder *g, int32_t *iu0, int32_t *iv0, int
             DevBuf<uint8_t> f(n);
             hipLaunchKernelGGL(k_binmap, blocks1d(n), dim3(256), 0, st, g->map, a.p, b.p, c.p, f.p);
             PFB_HIP(hipGetLastError());
-            if (iu0) PFB_HIP(hipMemcpyAsync(iu0, a.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            if (iv0) PFB_HIP(hipMemcpyAsync(iv0, b.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            // the plan's u is the caller's v
+            if (iu0) PFB_HIP(hipMemcpyAsync(iu0, b.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (iv0) PFB_HIP(hipMemcpyAsync(iv0, a.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
             if (p0) PFB_HIP(hipMemcpyAsync(p0, c.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
             if (flip) PFB_HIP(hipMemcpyAsync(flip, f.p, n, hipMemcpyDeviceToHost, st));
             PFB_HIP(hipStreamSynchronize(st));
@@ -1393,8 +1420,7 @@ int pfbhip_gridder_vis2dirty(pfbhip_gridder *g, const double *vis_host, const do
                                g->info.nactive, g->d_vis.p, wgt_host ? g->d_wgt.p : nullptr, int(g->shifting),
                                g->info.lshift, g->info.mshift, g->info.nshift, g->d_sval.p);
         PFB_HIP(hipGetLastError());
-        g->grid_all_planes(g->d_sval.p);
-        g->finalize(nullptr, 1.0, 0.0, nullptr, g->d_img.p);
+        g->grid_and_finalize(g->d_sval.p, nullptr, 1.0, 0.0, nullptr, g->d_img.p);
         PFB_HIP(hipMemcpyAsync(dirty_host, g->d_img.p, size_t(npix) * sizeof(double), hipMemcpyDeviceToHost, st));
         PFB_HIP(hipStreamSynchronize(st));
     });
@@ -1424,8 +1450,16 @@ int pfbhip_gridder_grid_plane(pfbhip_gridder *g, const double *vis_host, const d
             }
             PFB_HIP(hipGetLastError());
         }
-        PFB_HIP(hipMemcpyAsync(grid_host, g->d_grid.p, g->plane_stride * sizeof(double2), hipMemcpyDeviceToHost, st));
+        // the plan's plane is (nv, nu) in the caller's terms: transpose on the host (debug entry)
+        std::vector<double2> tmp(g->plane_stride);
+        PFB_HIP(hipMemcpyAsync(tmp.data(), g->d_grid.p, g->plane_stride * sizeof(double2), hipMemcpyDeviceToHost, st));
         PFB_HIP(hipStreamSynchronize(st));
+        const int64_t pu = g->info.nu, pv = g->info.nv;  // plan rows / columns = caller's nv / nu
+        double2 *out = reinterpret_cast<double2 *>(grid_host);
+        for (int64_t a0 = 0; a0 < pu; a0 += 32)
+            for (int64_t b0 = 0; b0 < pv; b0 += 32)
+                for (int64_t a = a0; a < std::min(a0 + 32, pu); ++a)
+                    for (int64_t b = b0; b < std::min(b0 + 32, pv); ++b) out[b * pu + a] = tmp[a * pv + b];
     });
 }
 
@@ -1437,8 +1471,7 @@ int pfbhip_gridder_dirty2vis(pfbhip_gridder *g, const double *dirty_host, const 
         const int64_t npix = g->prm.nx * g->prm.ny;
         PFB_HIP(hipMemcpyAsync(g->d_img.p, dirty_host, size_t(npix) * sizeof(double), hipMemcpyHostToDevice, st));
         g->upload_vis_wgt(nullptr, wgt_host);
-        g->prepare_degrid_input(g->d_img.p, nullptr);
-        g->degrid_all_planes(g->d_sacc.p);
+        g->prepare_and_degrid(g->d_img.p, nullptr, g->d_sacc.p);
         if (g->nvis) {
             g->d_vis.ensure(size_t(g->nvis));
             PFB_HIP(hipMemsetAsync(g->d_vis.p, 0, size_t(g->nvis) * sizeof(double2), st));
@@ -1475,16 +1508,14 @@ static void hessian_dev_impl(pfbhip_gridder *g, const double *x_dev, const doubl
     PFB_REQUIRE(g->weights_bound, "call pfbhip_gridder_set_weights before the Hessian");
     hipStream_t st = g->stream;
     const int64_t npix = g->prm.nx * g->prm.ny;
-    g->prepare_degrid_input(x_dev, beam_dev);
-    g->degrid_all_planes(g->d_sacc.p);
+    g->prepare_and_degrid(x_dev, beam_dev, g->d_sacc.p);
     g->timer.begin(5);
     if (g->info.nactive)
         hipLaunchKernelGGL(k_scale_sorted, blocks1d(g->info.nactive), dim3(256), 0, st, g->info.nactive, g->d_sacc.p,
                            g->d_swgt.p, g->d_sval.p);
     PFB_HIP(hipGetLastError());
     g->timer.end();
-    g->grid_all_planes(g->d_sval.p);
-    g->finalize(beam_dev, wsum > 0.0 ? 1.0 / wsum : 1.0, eta, eta != 0.0 ? x_dev : nullptr, out_dev);
+    g->grid_and_finalize(g->d_sval.p, beam_dev, wsum > 0.0 ? 1.0 / wsum : 1.0, eta, eta != 0.0 ? x_dev : nullptr, out_dev);
     (void)npix;
 }
 
@@ -1549,8 +1580,7 @@ int pfbhip_gridder_degrid_dev(pfbhip_gridder *g, const double *dirty_dev, double
 {
     return guarded([&] {
         PFB_REQUIRE(g && dirty_dev && vis_sorted_dev, "NULL argument");
-        g->prepare_degrid_input(dirty_dev, nullptr);
-        g->degrid_all_planes(reinterpret_cast<double2 *>(vis_sorted_dev));
+        g->prepare_and_degrid(dirty_dev, nullptr, reinterpret_cast<double2 *>(vis_sorted_dev));
         PFB_HIP(hipStreamSynchronize(g->stream));
     });
 }
@@ -1559,8 +1589,7 @@ int pfbhip_gridder_grid_dev(pfbhip_gridder *g, const double *vis_sorted_dev, dou
 {
     return guarded([&] {
         PFB_REQUIRE(g && dirty_dev && vis_sorted_dev, "NULL argument");
-        g->grid_all_planes(reinterpret_cast<const double2 *>(vis_sorted_dev));
-        g->finalize(nullptr, 1.0, 0.0, nullptr, dirty_dev);
+        g->grid_and_finalize(reinterpret_cast<const double2 *>(vis_sorted_dev), nullptr, 1.0, 0.0, nullptr, dirty_dev);
         PFB_HIP(hipStreamSynchronize(g->stream));
     });
 }

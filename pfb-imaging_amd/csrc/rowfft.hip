@@ -176,7 +176,7 @@ struct OccLoad {
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(const double2 *tw, FusedGeom g, const uint8_t *occ,
                                                           const double2 *B, size_t bstride, FusedPlanes planes,
-                                                          int do_w, int first, int lds_row, double *accT)
+                                                          int do_w, int first, int lds_row, double *accT, FusedFinal fin)
 {
     extern __shared__ double rf_lds[];
     double *acc = rf_lds + S::LDS_BYTES / sizeof(double);
@@ -201,16 +201,23 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
         // are in flight
 #pragma unroll
         for (int e0 = 0; e0 < S::E; e0 += 4) {
-            double old[4];
+            double old[4], cf[4];
+            const bool finalize = last && to_img && fin.corr != nullptr;
 #pragma unroll
             for (int e = e0; e < e0 + 4; ++e) {
                 const int ix = fg_ix(g, S::out_pos(t, e));
-                double o = 0.0;
+                double o = 0.0, c = 1.0;
                 if (ix >= 0) {
                     if (add_img) o = arow[ix];
                     if (add_lds) o += acc[ix];
+                    if (finalize) {  // correction (and beam) requested together with the running sums
+                        const size_t oo = size_t(y) * size_t(g.nx) + size_t(ix);
+                        c = fin.corr[oo];
+                        if (fin.beam != nullptr) c *= fin.beam[oo];
+                    }
                 }
                 old[e - e0] = o;
+                cf[e - e0] = c;
             }
 #pragma unroll
             for (int e = e0; e < e0 + 4; ++e) {
@@ -225,8 +232,18 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
                         r = im[e] * c + re[e] * s;  // Re( (im + i re) * (c - i s) )
                     }
                     r += old[e - e0];
-                    if (to_img) arow[ix] = r;
-                    else acc[ix] = r;
+                    if (to_img) {
+                        if (finalize) {  // finalize in place of a separate pass over the image
+                            const size_t o = size_t(y) * size_t(g.nx) + size_t(ix);
+                            double v = r * cf[e - e0] * fin.scale;
+                            if (fin.x != nullptr) v += fin.eta * fin.x[o];
+                            fin.out[o] = v;
+                        } else {
+                            arow[ix] = r;
+                        }
+                    } else {
+                        acc[ix] = r;
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);  // bound the number of sincos chains in flight
@@ -235,7 +252,8 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
 }
 
 struct PadLoad {
-    const double *drow;  // dcT row y
+    const double *drow;  // dcT row y (or, prep: the caller's image row)
+    const double *crow, *brow;  // prep: correction / beam rows (crow == NULL: drow is already prepared)
     double *lrow;        // LDS copy of the row (NULL: none); plane 0 fills it, the others read it
     const FusedGeom &g;  // the kernel argument itself (a copy would put the coefficient array in scratch)
     int y, do_w, k;
@@ -249,6 +267,10 @@ struct PadLoad {
             val = lrow[ix];
         } else {
             val = drow[ix];
+            if (crow != nullptr) {
+                val *= crow[ix];
+                if (brow != nullptr) val *= brow[ix];
+            }
             if (lrow != nullptr) lrow[ix] = val;  // thread-private cell: the same thread asks for it on every plane
         }
         if (!do_w) return make_double2(val, 0.0);
@@ -262,8 +284,8 @@ struct PadLoad {
 
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const double2 *tw, FusedGeom g, const uint8_t *occ,
-                                                         const double *dcT, FusedPlanes planes, int do_w, int lds_row,
-                                                         double2 *B, size_t bstride)
+                                                         const double *dcT, FusedPrep prep, FusedPlanes planes, int do_w,
+                                                         int lds_row, double2 *B, size_t bstride)
 {
     extern __shared__ double rf_lds[];
     double *lrow = lds_row ? rf_lds + S::LDS_BYTES / sizeof(double) : nullptr;
@@ -272,7 +294,9 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
 #pragma unroll
     for (int e = 0; e < S::E; ++e) omask |= (occ[S::out_pos(int(threadIdx.x), e) >> 5] ? 1u : 0u) << e;
     for (int k = 0; k < planes.kp; ++k) {
-        PadLoad ld{dcT + size_t(y) * g.nx, lrow, g, y, do_w, k, planes.w[k]};
+        const size_t ro = size_t(y) * size_t(g.nx);
+        PadLoad ld{prep.x != nullptr ? prep.x + ro : dcT + ro, prep.x != nullptr ? prep.corr + ro : nullptr,
+                   (prep.x != nullptr && prep.beam != nullptr) ? prep.beam + ro : nullptr, lrow, g, y, do_w, k, planes.w[k]};
         double re[S::E], im[S::E];
         int t;
         rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
@@ -355,35 +379,36 @@ static bool fused_row_fits(int N, int nx) { return (size_t(N) + size_t(nx)) * si
 template <class S>
 static void launch_crop(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev,
                         size_t bstride, const FusedPlanes &planes, int do_w, bool first, double *accT_dev,
-                        hipStream_t stream)
+                        const FusedFinal &fin, hipStream_t stream)
 {
     static bool attr = false;
     rf_allow_lds(&k_fused_fft_crop<S>, &attr);
     const bool row = fused_row_fits(S::N, g.nx) && planes.kp > 1;
     const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
     hipLaunchKernelGGL(k_fused_fft_crop<S>, dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
-                       bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev);
+                       bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin);
 }
 
 template <class S>
 static void launch_pad(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev,
-                       const FusedPlanes &planes, int do_w, double2 *B_dev, size_t bstride, hipStream_t stream)
+                       const FusedPrep &prep, const FusedPlanes &planes, int do_w, double2 *B_dev, size_t bstride,
+                       hipStream_t stream)
 {
     static bool attr = false;
     rf_allow_lds(&k_fused_pad_fft<S>, &attr);
     const bool row = fused_row_fits(S::N, g.nx) && planes.kp > 1;
     const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
     hipLaunchKernelGGL(k_fused_pad_fft<S>, dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
-                       planes, do_w, row ? 1 : 0, B_dev, bstride);
+                       prep, planes, do_w, row ? 1 : 0, B_dev, bstride);
 }
 
 void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev, size_t bstride,
-                    const FusedPlanes &planes, int do_w, bool first, double *accT_dev, hipStream_t stream)
+                    const FusedPlanes &planes, int do_w, bool first, double *accT_dev, const FusedFinal &fin, hipStream_t stream)
 {
     switch (f.pl.N) {
 #define RF_X(L, K)                                                                                                   \
     case (L << K):                                                                                                   \
-        launch_crop<RfShape<L, K, false>>(f.pl, g, occ_dev, B_dev, bstride, planes, do_w, first, accT_dev, stream); \
+        launch_crop<RfShape<L, K, false>>(f.pl, g, occ_dev, B_dev, bstride, planes, do_w, first, accT_dev, fin, stream); \
         break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X
@@ -392,13 +417,13 @@ void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev,
     PFB_HIP(hipGetLastError());
 }
 
-void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev,
+void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev, const FusedPrep &prep,
                    const FusedPlanes &planes, int do_w, double2 *B_dev, size_t bstride, hipStream_t stream)
 {
     switch (f.pl.N) {
 #define RF_X(L, K)                                                                                           \
     case (L << K):                                                                                           \
-        launch_pad<RfShape<L, K, false>>(f.pl, g, occ_dev, dcT_dev, planes, do_w, B_dev, bstride, stream); \
+        launch_pad<RfShape<L, K, false>>(f.pl, g, occ_dev, dcT_dev, prep, planes, do_w, B_dev, bstride, stream); \
         break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X

@@ -31,6 +31,18 @@ struct FusedGeom {
 };
 // Fit the polynomial of g.pc over the field of view of g (absolute error <= 4e-16 max|n - 1|), or leave npoly = 0.
 void fused_geom_fit(FusedGeom &g);
+// Image-side element-wise steps folded into the fused kernels (the plan's accT layout is the caller's image
+// layout).  FusedPrep: the degrid input row is x * corr [* beam] read straight from the caller's image instead
+// of a prepared copy.  FusedFinal: the LAST grid launch writes out = sum * corr [* beam] * scale + eta * x
+// instead of the raw accumulator.
+struct FusedPrep {
+    const double *x = nullptr, *corr = nullptr, *beam = nullptr;  // x == NULL: disabled (read the prepared accT)
+};
+struct FusedFinal {
+    const double *corr = nullptr, *beam = nullptr, *x = nullptr;  // corr == NULL: disabled (write accT)
+    double scale = 1.0, eta = 0.0;
+    double *out = nullptr;
+};
 constexpr int FUSED_MAXPLANES = 4;
 struct FusedPlanes {
     int kp;
@@ -41,10 +53,10 @@ struct FusedPlanes {
 // columns that are not occupied are taken as zero without being read), then
 // accT[y][x] (+)= Re( out[wrap(x - nx/2)] * exp(-2 pi i w_k t(x, y)) ).  first: plane 0 overwrites accT.
 void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev, size_t bstride,
-                    const FusedPlanes &pl, int do_w, bool first, double *accT_dev, hipStream_t stream);
+                    const FusedPlanes &pl, int do_w, bool first, double *accT_dev, const FusedFinal &fin, hipStream_t stream);
 // degrid side: for every image row y and plane k: B_k[y][wrap(x - nx/2)] = dcT[y][x] exp(+2 pi i w_k t), 0
 // elsewhere, forward row FFT, and only the occupied 32-column blocks of the result are written.
-void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev,
+void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev, const FusedPrep &prep,
                    const FusedPlanes &pl, int do_w, double2 *B_dev, size_t bstride, hipStream_t stream);
 
 }  // namespace pfbhip

@@ -10,6 +10,8 @@
 //   iu0     = (int) floor(pu + (1 - W/2))        first of W taps (may be < 0; taps wrap mod nu)
 //   pw      = (w - wmin) * (1/dw) ;  p0 = (int) floor(pw + (1 - W/2))
 //   tile    = (wrap(iu0, nu) / T) * ntv + wrap(iv0, nv) / T
+// The gridder runs the TRANSPOSED problem internally (swap_uv: its "u" is the caller's v); every formula
+// above is symmetric in the two axes, so the caller's (iu0, iv0) are the plan's (iv0, iu0), bit for bit.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -35,6 +37,7 @@ struct MapArgs {
     int W;
     int do_w;
     double wmin, xdw;
+    int swap_uv;      // 1: the plan works on the transposed problem (u <-> v exchanged at the C-ABI boundary, see gridder.hip)
 };
 
 struct VisPos {
@@ -56,8 +59,9 @@ __device__ __forceinline__ VisPos vis_position(const MapArgs &m, int64_t i)
     int64_t row = i / m.nchan;
     int chan = int(i - row * m.nchan);
     double f = m.fc[chan];
-    double u = m.uvw[3 * row] * m.su;
-    double v = m.uvw[3 * row + 1] * m.sv;
+    const int cu = m.swap_uv ? 1 : 0;
+    double u = m.uvw[3 * row + cu] * m.su;
+    double v = m.uvw[3 * row + 1 - cu] * m.sv;
     double w = m.uvw[3 * row + 2] * m.sw;
     u = u * f;
     v = v * f;

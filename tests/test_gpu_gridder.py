@@ -59,10 +59,14 @@ def test_binmap_bit_exact(center, do_w):
     assert np.array_equal(bm["iv0"], o.iv0)
     assert np.array_equal(bm["p0"], o.p0)
     assert np.array_equal(bm["flip"], o.flip)
-    # same set of active visibilities, tile ids non-decreasing along the GPU's sorted order
+    # same set of active visibilities; the plan sorts by the tile id of the TRANSPOSED problem it works on
+    # (v-tile major): the oracle's (u-tile, v-tile) pair re-keyed that way is non-decreasing along the GPU's order
     assert g.nactive == int(o.active.sum())
     assert np.array_equal(np.sort(bm["order"]), np.flatnonzero(o.active))
-    tiles = o.tile_id[bm["order"]]
+    ntv = -(-g.info["nv"] // 32)
+    ntu = -(-g.info["nu"] // 32)
+    tu, tv = o.tile_id // ntv, o.tile_id % ntv
+    tiles = (tv * ntu + tu)[bm["order"]]
     assert np.all(np.diff(tiles) >= 0)
     g.close()
 
