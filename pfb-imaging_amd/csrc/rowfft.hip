@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -374,7 +375,13 @@ void fused_geom_fit(FusedGeom &g)
 
 // The fused kernels transpose one component at a time (N doubles of LDS), which leaves room for the
 // workgroup's image row (nx doubles) when (N + nx) * 8 <= 160 KiB.
-static bool fused_row_fits(int N, int nx) { return (size_t(N) + size_t(nx)) * sizeof(double) <= 160 * 1024; }
+static bool fused_row_fits(int N, int nx)
+{
+    // PFBHIP_FUSED_LDSROW=0 forces the read-modify-write form (what large grids use) so that tests reach it
+    const char *env = std::getenv("PFBHIP_FUSED_LDSROW");
+    if (env != nullptr && env[0] == '0') return false;
+    return (size_t(N) + size_t(nx)) * sizeof(double) <= 160 * 1024;
+}
 
 template <class S>
 static void launch_crop(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev,

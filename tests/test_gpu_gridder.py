@@ -426,3 +426,26 @@ def test_epsilon_contract_own_fft_path(eps):
     rhs = np.vdot(c["x"], g.vis2dirty(y))
     assert abs(lhs - rhs) <= 1e-9 * abs(rhs)
     g.close()
+
+
+def test_fused_rmw_form_matches_lds_row_form(monkeypatch):
+    """Grids too large for the LDS image row use the read-modify-write form of the fused kernels (every plane
+    updates the accumulator, the last one finalizes): forced here with PFBHIP_FUSED_LDSROW=0, many ES-kernel
+    planes in several launches, with beam and eta through the Hessian."""
+    from pfb_imaging_amd.wgridder import Gridder
+
+    c = make(nrow=1500, npix=1024, widen=60.0, zscale=1.0)
+    kw = dict(npix_x=c["nx"], npix_y=c["ny"], pixsize_x=c["cell"], pixsize_y=c["cell"], epsilon=1e-7, flip_v=True,
+              do_wgridding=True, divide_by_n=False)
+    rng = np.random.default_rng(3)
+    beam = 0.5 + rng.random((c["nx"], c["ny"]))
+    res = {}
+    for env in ("1", "0"):
+        monkeypatch.setenv("PFBHIP_FUSED_LDSROW", env)
+        g = Gridder(c["uvw"], c["freq"], c["mask"], **kw)
+        assert g.info["fft_mode"] == 3 and g.info["nplanes"] > 8
+        g.set_weights(c["wgt"])
+        res[env] = (g.vis2dirty(c["vis"], c["wgt"]), g.dirty2vis(c["x"]), g.hessian(c["x"], beam=beam, eta=0.3, wsum=7.0))
+        g.close()
+    for a, b in zip(res["1"], res["0"]):
+        assert rel(a, b) < 1e-11  # different summation order over ~180 planes, edge-amplified (see test_fused_row_fft_path)
