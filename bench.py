@@ -62,8 +62,11 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
             "fft_rows": 2 * occ * G,                                  # first axis, one plane: read + write of the occupied rows
             "pad": occ * B + occ * G,                                 # B -> A transpose with zero padding, one plane
             "crop": occ * (ny / info["nv"]) * G + occ * B,            # A -> B transpose with crop, one plane
-            "fft_crop": ppl * occ * B + I * (2 - 1 / ngroups),        # planes read once; image written (first group) or read+written
-            "pad_fft": I + ppl * occ * B,                             # image read once per launch; occupied columns written per plane
+            # planes read once; image written (first group) or read+written; the last launch also reads the correction
+            # image (the finalize is folded into it)
+            "fft_crop": ppl * occ * B + I * (2 - 1 / ngroups) + I / ngroups,
+            # image and correction image read once per launch (x * corr is formed in the load); occupied columns written per plane
+            "pad_fft": 2 * I + ppl * occ * B,
         })
     else:
         per_launch.update({
