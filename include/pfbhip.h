@@ -285,7 +285,11 @@ int pfbhip_positivity_dev(double *x_dev, int64_t nband, int64_t n, int mode);
  * eta[b] x from the slots of band b's plan pcs[b] (one plan for all bands -- HessPSF -- or one per band --
  * HessTreeRay; band b owns nparts[b] consecutive entries of psf_slots / beam_slots, as in pfbhip_psfconv_cg).  x (nband, nx, ny): initial iterate in, solution out; v (nband, nbasis, nxmax, nymax):
  * warm-started dual in / out; weight (nbasis, nxmax, nymax); positivity 0 | 1 | 2 (prox/positivity.py).
- * Stops when ||x - xp|| / ||x|| < tol or after maxit iterations; info->iters is the last loop index. */
+ * Stops when ||x - xp|| / ||x|| < tol or after maxit iterations; info->iters is the last loop index.
+ * comm == NULL: all nband bands are on this device.  comm != NULL (one process per GPU, every rank calls
+ * collectively): the arrays hold this rank's nband LOCAL bands; the band sum of the dual update, the
+ * "any band <= 0" test of positivity mode 2 and the convergence norms are completed with all-reduces. */
+typedef struct pfbhip_comm pfbhip_comm; /* RCCL communicator, see below */
 typedef struct pfbhip_pd_info {
     int32_t iters;
     int32_t status; /* 0 converged, 1 maxit reached */
@@ -294,7 +298,7 @@ typedef struct pfbhip_pd_info {
 int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs /* [nband] */, int64_t nband, const int64_t *nparts, const int64_t *psf_slots,
                        const int64_t *beam_slots, const double *scale, const double *eta, const double *xtilde_host, double gamma,
                        double *x_host, double *v_host, const double *weight_host, double lam, double sigma, double tau,
-                       int positivity, double tol, int maxit, pfbhip_pd_info *info);
+                       int positivity, double tol, int maxit, pfbhip_comm *comm, pfbhip_pd_info *info);
 
 /* ---- band reduce over xGMI (RCCL) ------------------------------------ */
 /*
@@ -304,7 +308,6 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs /* [nband] */
  * rank 0 and carried to the other ranks by the caller's launcher (torchrun /
  * any store).
  */
-typedef struct pfbhip_comm pfbhip_comm;
 #define PFBHIP_UNIQUE_ID_BYTES 128
 int pfbhip_comm_unique_id(uint8_t *id /* [PFBHIP_UNIQUE_ID_BYTES] */);
 int pfbhip_comm_create(const uint8_t *id, int nranks, int rank, pfbhip_comm **out);

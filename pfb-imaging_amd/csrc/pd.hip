@@ -13,12 +13,20 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <stdexcept>
+#include <string>
 #include <utility>
 #include <vector>
 
 #include "common.hpp"
 #include "devcg.hpp"
 #include "pipeline_api.hpp"
+
+// a failed C-ABI call inside the driver (its message is already in pfbhip_last_error())
+#define PFB_CHECK_STATUS(call)                                                    \
+    do {                                                                          \
+        if ((call) != 0) throw std::runtime_error(std::string(pfbhip_last_error())); \
+    } while (0)
 
 namespace pfbhip {
 
@@ -56,7 +64,7 @@ extern "C" {
 int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nband, const int64_t *nparts, const int64_t *psf_slots,
                        const int64_t *beam_slots, const double *scale, const double *eta, const double *xtilde_host, double gamma,
                        double *x_host, double *v_host, const double *weight_host, double lam, double sigma, double tau,
-                       int positivity, double tol, int maxit, pfbhip_pd_info *info)
+                       int positivity, double tol, int maxit, pfbhip_comm *comm, pfbhip_pd_info *info)
 {
     return guarded([&] {
         PFB_REQUIRE(psi && pcs && nparts && psf_slots && beam_slots && scale && eta && xtilde_host && x_host && v_host &&
@@ -101,6 +109,7 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
         // Buffer rotation instead of copies: xa / xb alternate as (x, xp); va / vb alternate as (dual, previous
         // dual); vext holds the extrapolated dual 2 v - vp of the current iteration.
         DevBuf<double> xa(nimg), xb(nimg), xout(nimg), xt(nimg), d(npix), va(ncoef), vb(ncoef), vext(ncoef), w(cube);
+        DevBuf<double> sum(comm != nullptr ? cube : 0);
         DevBuf<double> partials(3 * size_t(CG_BLOCKS));
         std::vector<double> hpart(3 * size_t(CG_BLOCKS));
         double *xp = xa.p, *x = xb.p, *vp = va.p, *v = vb.p;
@@ -118,8 +127,16 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
         int k = 0, status = 1;
         for (; k < maxit; ++k) {
             for (int64_t b = 0; b < nband; ++b) psi_dot_async(psi, xp + size_t(b) * npix, v + size_t(b) * cube);
-            // v <- dual update(vp, Psi^H xp) ; vext <- 2 v - vp   (one pass over the cubes)
-            l21_fused_async(vp, v, vext.p, nband, int64_t(cube), lam, sigma, w.p, st);
+            // v <- dual update(vp, Psi^H xp) ; vext <- 2 v - vp
+            if (comm == nullptr) {
+                l21_fused_async(vp, v, vext.p, nband, int64_t(cube), lam, sigma, w.p, st);  // one pass over the cubes
+            } else {
+                // the bands of this rank only: the band sum of vtilde is completed with ONE all-reduce per iteration
+                l21_localsum_async(vp, v, nband, int64_t(cube), sigma, sum.p, st);
+                PFB_HIP(hipStreamSynchronize(st));
+                PFB_CHECK_STATUS(pfbhip_comm_allreduce_sum(comm, sum.p, sum.p, int64_t(cube)));
+                l21_apply_async(vp, v, vext.p, nband, int64_t(cube), lam, sigma, w.p, sum.p, st);
+            }
             for (int64_t b = 0; b < nband; ++b) {
                 double *xo = xout.p + size_t(b) * npix;
                 psi_hdot_async(psi, vext.p + size_t(b) * cube, xo);
@@ -130,7 +147,14 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
                                         q == off[size_t(b)] ? -eta[b] / gamma : 0.0, 1, xo);
             }
             hipLaunchKernelGGL(k_pd_primal, blocks(nimg), dim3(256), 0, st, x, xp, xout.p, tau, int64_t(nimg));
-            if (positivity) positivity_async(x, nband, int64_t(npix), positivity, st);
+            if (positivity == 2 && comm != nullptr) {  // "any band <= 0" spans the ranks
+                positivity_flag_async(x, nband, int64_t(npix), d.p, st);
+                PFB_HIP(hipStreamSynchronize(st));
+                PFB_CHECK_STATUS(pfbhip_comm_allreduce_sum(comm, d.p, d.p, int64_t(npix)));
+                positivity_zero_async(x, nband, int64_t(npix), d.p, st);
+            } else if (positivity) {
+                positivity_async(x, nband, int64_t(npix), positivity, st);
+            }
             hipLaunchKernelGGL(k_pd_norms, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, st, int64_t(nimg), x, xp, partials.p);
             PFB_HIP(hipGetLastError());
             PFB_HIP(hipMemcpyAsync(hpart.data(), partials.p, hpart.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -140,6 +164,17 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
                 num += hpart[size_t(i)];
                 den += hpart[size_t(CG_BLOCKS) + size_t(i)];
                 nnz += hpart[2 * size_t(CG_BLOCKS) + size_t(i)];
+            }
+            if (comm != nullptr) {  // the norms are over ALL bands
+                const double loc[3] = {num, den, nnz};
+                double tot[3];
+                PFB_HIP(hipMemcpyAsync(partials.p, loc, sizeof loc, hipMemcpyHostToDevice, st));
+                PFB_HIP(hipStreamSynchronize(st));
+                PFB_CHECK_STATUS(pfbhip_comm_allreduce_sum(comm, partials.p, partials.p, 3));
+                PFB_HIP(hipMemcpy(tot, partials.p, sizeof tot, hipMemcpyDeviceToHost));
+                num = tot[0];
+                den = tot[1];
+                nnz = tot[2];
             }
             eps = nnz > 0.0 ? std::sqrt(num / std::max(den, 1e-12)) : 1.0;  // _nb_norm_diff, primal_dual.py:40-52, 429
             if (eps < tol) {

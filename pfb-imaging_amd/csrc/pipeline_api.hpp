@@ -23,7 +23,15 @@ void l21_scale_async(double *v_dev, int64_t nband, int64_t n, double lam, const 
 // a = Psi^H xp in; a = updated dual, ext = 2 a - vp out (all bands on this device)
 void l21_fused_async(const double *vp_dev, double *a_dev, double *ext_dev, int64_t nband, int64_t n, double lam, double sigma,
                      const double *weight_dev, hipStream_t st);
+// bands spread over ranks: local band sum of vtilde, then (given the all-reduced sum) the update + extrapolation
+void l21_localsum_async(const double *vp_dev, const double *a_dev, int64_t nband, int64_t n, double sigma, double *sum_dev,
+                        hipStream_t st);
+void l21_apply_async(const double *vp_dev, double *a_dev, double *ext_dev, int64_t nband, int64_t n, double lam, double sigma,
+                     const double *weight_dev, const double *sum_dev, hipStream_t st);
 void positivity_async(double *x_dev, int64_t nband, int64_t n, int mode, hipStream_t st);
+// positivity mode 2 across ranks: flag pixels with a non-positive LOCAL band; zero all local bands where the (summed) flag > 0
+void positivity_flag_async(const double *x_dev, int64_t nband, int64_t n, double *bad_dev, hipStream_t st);
+void positivity_zero_async(double *x_dev, int64_t nband, int64_t n, const double *bad_dev, hipStream_t st);
 
 // PSF convolution (psfconv.hip)
 hipStream_t psfconv_stream(pfbhip_psfconv *p);

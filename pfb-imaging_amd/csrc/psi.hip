@@ -205,6 +205,49 @@ __global__ void __launch_bounds__(256) k_l21_fused(const double *__restrict__ vp
     }
 }
 
+// bands spread over ranks: (1) the LOCAL band sum of vtilde, (2) -- after the all-reduce -- the update itself
+__global__ void __launch_bounds__(256) k_l21_localsum(const double *__restrict__ vp, const double *__restrict__ a, int nband,
+                                                       int64_t n, double sigma, double *__restrict__ sum)
+{
+    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nband; ++b) s += vp[size_t(b) * size_t(n) + size_t(i)] + sigma * a[size_t(b) * size_t(n) + size_t(i)];
+    sum[i] = s;
+}
+__global__ void __launch_bounds__(256) k_l21_apply(const double *__restrict__ vp, double *__restrict__ a, double *__restrict__ ext,
+                                                    int nband, int64_t n, double lam, double sigma,
+                                                    const double *__restrict__ weight, const double *__restrict__ sum)
+{
+    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (i >= n) return;
+    const double as = fabs(sum[i]), thr = lam * weight[i];
+    const double sc = as > thr ? thr / as : 1.0;
+    for (int b = 0; b < nband; ++b) {
+        const size_t o = size_t(b) * size_t(n) + size_t(i);
+        const double p = vp[o];
+        const double vn = (p + sigma * a[o]) * sc;
+        a[o] = vn;
+        ext[o] = 2.0 * vn - p;
+    }
+}
+// positivity mode 2 across ranks: (1) bad[i] = 1 if any LOCAL band is <= 0, (2) zero where the all-reduced count > 0
+__global__ void __launch_bounds__(256) k_pos_flag(const double *__restrict__ x, int nband, int64_t n, double *__restrict__ bad)
+{
+    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (i >= n) return;
+    bool b0 = false;
+    for (int b = 0; b < nband; ++b) b0 = b0 || x[size_t(b) * size_t(n) + size_t(i)] <= 0.0;
+    bad[i] = b0 ? 1.0 : 0.0;
+}
+__global__ void __launch_bounds__(256) k_pos_zero(double *__restrict__ x, int nband, int64_t n, const double *__restrict__ bad)
+{
+    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (i >= n) return;
+    if (bad[i] > 0.0)
+        for (int b = 0; b < nband; ++b) x[size_t(b) * size_t(n) + size_t(i)] = 0.0;
+}
+
 // prox_{sigma ||.||_21}(v): v * max(|s| - sigma w, 0) / |s|, s = band sum (prox_21m.py:5-26)
 __global__ void __launch_bounds__(256) k_prox21(const double *__restrict__ v, int nband, int64_t n, double sigma,
                                                 const double *__restrict__ weight, double *__restrict__ out)
@@ -366,6 +409,30 @@ void l21_fused_async(const double *vp_dev, double *a_dev, double *ext_dev, int64
 {
     hipLaunchKernelGGL(k_l21_fused, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, st, vp_dev, a_dev, ext_dev, int(nband), n, lam,
                        sigma, weight_dev);
+    PFB_HIP(hipGetLastError());
+}
+void l21_localsum_async(const double *vp_dev, const double *a_dev, int64_t nband, int64_t n, double sigma, double *sum_dev,
+                        hipStream_t st)
+{
+    hipLaunchKernelGGL(k_l21_localsum, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, st, vp_dev, a_dev, int(nband), n, sigma,
+                       sum_dev);
+    PFB_HIP(hipGetLastError());
+}
+void l21_apply_async(const double *vp_dev, double *a_dev, double *ext_dev, int64_t nband, int64_t n, double lam, double sigma,
+                     const double *weight_dev, const double *sum_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_l21_apply, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, st, vp_dev, a_dev, ext_dev, int(nband), n, lam,
+                       sigma, weight_dev, sum_dev);
+    PFB_HIP(hipGetLastError());
+}
+void positivity_flag_async(const double *x_dev, int64_t nband, int64_t n, double *bad_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pos_flag, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, st, x_dev, int(nband), n, bad_dev);
+    PFB_HIP(hipGetLastError());
+}
+void positivity_zero_async(double *x_dev, int64_t nband, int64_t n, const double *bad_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pos_zero, dim3(uint32_t(ceil_div(n, 256))), dim3(256), 0, st, x_dev, int(nband), n, bad_dev);
     PFB_HIP(hipGetLastError());
 }
 void positivity_async(double *x_dev, int64_t nband, int64_t n, int mode, hipStream_t st)

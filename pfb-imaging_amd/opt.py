@@ -124,24 +124,26 @@ class PrimalDual:
     # ---- device-resident loop --------------------------------------------------------------
     @staticmethod
     def _hess_bands(hess, nband):
-        """Per band: (plan handle owner, psf slots, beam slots, scale, eta) of a device-resident PSF Hessian, or
-        None if ``hess`` is not one this process holds completely (HessPSF; HessTreeRay over a local pool)."""
+        """(bands, comm, local): per LOCAL band (plan, psf slots, beam slots, scale, eta) of a device-resident PSF
+        Hessian -- HessPSF (all bands here, comm None) or HessTreeRay (this rank's bands of its pool) -- or None."""
         from .operators.hessian import HessPSF, HessTreeRay
 
         if isinstance(hess, HessPSF) and hess.nband == nband:
-            return [(hess._plan, [b], [-1 if hess.beam[b] is None else b], 1.0, float(hess.eta[b])) for b in range(nband)]
+            bands = [(hess._plan, [b], [-1 if hess.beam[b] is None else b], 1.0, float(hess.eta[b])) for b in range(nband)]
+            return bands, None, list(range(nband))
         if isinstance(hess, HessTreeRay) and hess.nband == nband:
             pool = hess._pool
-            if pool.comm is not None and pool.comm.world_size > 1:
-                return None  # bands live on other ranks: the generic loop runs them through the pool
+            comm = pool.comm if (pool.comm is not None and pool.comm.world_size > 1) else None
+            if comm is not None and (comm.transport != "rccl" or not pool.local):
+                return None  # CPU transport (tests) or a rank without bands: the generic loop handles it
             out = []
-            for b in range(nband):
+            for b in pool.local:
                 tree = getattr(pool.workers[b], "_hess", None)
                 if tree is None or tree.ncorr != 1:
                     return None
                 s = tree._slots(0)
                 out.append((tree._plan, s, s, 1.0 / float(tree.wsum[0]), float(tree.eta)))
-            return out
+            return out, comm, list(pool.local)
         return None
 
     def _device_path(self):
@@ -158,28 +160,38 @@ class PrimalDual:
 
     def _solve_device(self, x, lam, mode):
         reg, psi = self._reg, self._reg.psi
-        nband = psi.nband
-        bands = self._hess_bands(self._grad.hess, nband)
+        bands, comm, local = self._hess_bands(self._grad.hess, psi.nband)
+        nloc = len(local)
         transposed = isinstance(psi, Psi)
-        v = self._v.transpose(0, 1, 3, 2) if transposed else self._v
+        vfull = self._v.transpose(0, 1, 3, 2) if transposed else self._v
         w = reg.l1weight.transpose(0, 2, 1) if transposed else reg.l1weight
-        v = np.ascontiguousarray(v, dtype=np.float64)
+        v = np.ascontiguousarray(vfull[local], dtype=np.float64)
         w = np.ascontiguousarray(np.broadcast_to(w, v.shape[1:]), dtype=np.float64)
-        xs = np.ascontiguousarray(x, dtype=np.float64).copy()
-        handles = (ct.c_void_p * nband)(*[b[0]._h for b in bands])
+        xs = np.ascontiguousarray(np.asarray(x, dtype=np.float64)[local])
+        xt = np.ascontiguousarray(self._grad.xtilde[local])
+        handles = (ct.c_void_p * nloc)(*[b[0]._h for b in bands])
         nparts = np.array([len(b[1]) for b in bands], dtype=np.int64)
         psf_slots = np.array([s for b in bands for s in b[1]], dtype=np.int64)
         beam_slots = np.array([s for b in bands for s in b[2]], dtype=np.int64)
         scale = np.array([b[3] for b in bands], dtype=np.float64)
         eta = np.array([b[4] for b in bands], dtype=np.float64)
         info = PDInfo()
-        check(lib().pfbhip_primal_dual(psi._band._h, handles, i64(nband), ptr(nparts), ptr(psf_slots), ptr(beam_slots),
-                                       ptr(scale), ptr(eta), ptr(self._grad.xtilde), f64(self._grad.gamma), ptr(xs), ptr(v),
+        check(lib().pfbhip_primal_dual(psi._band._h, handles, i64(nloc), ptr(nparts), ptr(psf_slots), ptr(beam_slots),
+                                       ptr(scale), ptr(eta), ptr(xt), f64(self._grad.gamma), ptr(xs), ptr(v),
                                        ptr(w), f64(lam), f64(self.sigma), f64(self.tau), cint(mode), f64(self.tol),
-                                       cint(self.maxit), ct.byref(info)))
-        self._v[...] = v.transpose(0, 1, 3, 2) if transposed else v
+                                       cint(self.maxit), None if comm is None else comm._h, ct.byref(info)))
+        if comm is None:
+            xall, vall = xs, v
+        else:  # every rank holds the full cubes again: each band was produced by exactly one rank
+            xall = np.zeros(x.shape)
+            xall[local] = xs
+            xall = comm.allreduce_sum(xall).reshape(x.shape)
+            vall = np.zeros(vfull.shape)
+            vall[local] = v
+            vall = comm.allreduce_sum(vall).reshape(vfull.shape)
+        self._v[...] = vall.transpose(0, 1, 3, 2) if transposed else vall
         self.last = dict(iters=info.iters, status=info.status, eps=info.eps)
-        x[...] = xs
+        x[...] = xall
         return x
 
     # ---- the reference's loop (any gradient callable) ----------------------------------------

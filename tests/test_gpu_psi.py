@@ -283,3 +283,42 @@ def test_primal_dual_device_loop_hess_tree_ray():
         res[name] = (pd.solve(model.copy(), 0.02), pd.last["iters"])
     assert res["device"][1] == res["generic"][1]
     assert rel(res["device"][0], res["generic"][0]) < 1e-9
+
+
+def test_primal_dual_device_loop_with_communicator():
+    """The band-per-rank form of the device loop (local band sum + all-reduce + update; all-reduced norms and
+    positivity flags) on a 1-rank RCCL communicator: every collective is executed, results equal the
+    single-process form."""
+    from pfb_imaging_amd import prox
+    from pfb_imaging_amd.operators.band_worker import BandWorkerPool
+    from pfb_imaging_amd.operators.hessian import HessTreeRay
+    from pfb_imaging_amd.operators.psi import PsiNocopyt
+    from pfb_imaging_amd.opt import L21, PrimalDual, PsfGrad
+    from pfb_imaging_amd.parallel import BandComm
+
+    nband, nx, ny, nxp, nyp = 2, 32, 48, 64, 96
+    bases = ("self", "db2")
+    rng = np.random.default_rng(6)
+    parts = [[{"psfhat": 1.0 + 0.1 * np.abs(rng.standard_normal((1, nxp, nyp // 2 + 1))), "beam": np.ones((1, nx, ny)),
+               "wsum": np.array([1.0])}] for _ in range(nband)]
+    model = np.abs(rng.standard_normal((nband, nx, ny))) * (rng.random((nband, nx, ny)) > 0.8)
+    xtilde = model + 0.3 * rng.standard_normal(model.shape)
+    res = {}
+    for name in ("plain", "comm"):
+        comm = BandComm.from_env(transport="rccl") if name == "comm" else None
+        pool = BandWorkerPool(nband, comm=comm)
+        hess = HessTreeRay(parts, nx, ny, nxp, nyp, etas=0.05, workers=pool)
+        psi = PsiNocopyt(nband, nx, ny, bases, 2, 1)
+        reg = L21(psi, bases, nu=np.sqrt(2.0))
+        pd = PrimalDual(tol=1e-8, maxit=15, verbosity=0, gamma=1.0, primal_prox=prox.positivity_band)
+        pd.setup(reg, 1.3)
+        pd.set_grad(PsfGrad(hess, xtilde, 1.0))
+        assert pd._device_path() == 2
+        if name == "comm":  # a 1-rank communicator is "world_size 1": force the collective code path
+            bands, _, local = pd._hess_bands(hess, nband)
+            pd._hess_bands = lambda h, n: (bands, comm, local)
+        res[name] = (pd.solve(model.copy(), 0.02), pd._v.copy(), pd.last["iters"])
+        if comm is not None:
+            comm.close()
+    assert res["plain"][2] == res["comm"][2]
+    assert rel(res["comm"][0], res["plain"][0]) < 1e-13 and rel(res["comm"][1], res["plain"][1]) < 1e-13
