@@ -449,3 +449,34 @@ def test_fused_rmw_form_matches_lds_row_form(monkeypatch):
         g.close()
     for a, b in zip(res["1"], res["0"]):
         assert rel(a, b) < 1e-11  # different summation order over ~180 planes, edge-amplified (see test_fused_row_fft_path)
+
+
+@pytest.mark.parametrize("flips", [(False, True, False), (True, False, False), (True, True, True), (False, False, False)])
+def test_anisotropic_pixels_and_flips_vs_dft(flips):
+    """Different pixel sizes, image sizes, centre offsets and flip conventions per axis -- everything the
+    plan's internal axis exchange has to carry over -- against the direct DFT (both directions)."""
+    flip_u, flip_v, flip_w = flips
+    c = make(nrow=1200, npix=64, widen=25.0, zscale=0.2)
+    rng = np.random.default_rng(12)
+    nx, ny = 72, 50
+    px, py = c["cell"] * 0.8, c["cell"] * 1.3
+    cx, cy = 0.011, -0.007
+    x = rng.standard_normal((nx, ny))
+    from pfb_imaging_amd.wgridder import Gridder
+
+    g = Gridder(c["uvw"], c["freq"], c["mask"], npix_x=nx, npix_y=ny, pixsize_x=px, pixsize_y=py, center_x=cx, center_y=cy,
+                epsilon=1e-8, flip_u=flip_u, flip_v=flip_v, flip_w=flip_w, do_wgridding=True, divide_by_n=False)
+    assert g.info["nu"] >= nx and g.info["nv"] >= ny and g.info["nu"] > g.info["nv"]
+    d = g.vis2dirty(c["vis"], c["wgt"])
+    ref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], c["mask"], nx, ny, px, py, cx, cy, flip_u, flip_v, flip_w,
+                            True, False)
+    assert d.shape == (nx, ny) and rel(d, ref) < 1e-8
+    v = g.dirty2vis(x)
+    refv = dft.dft_dirty2vis(c["uvw"], c["freq"], x, px, py, cx, cy, flip_u, flip_v, flip_w, True, False)
+    refv[c["mask"] == 0] = 0
+    assert rel(v, refv) < 1e-8
+    o = owg.Plan(c["uvw"], c["freq"], c["mask"], nx, ny, px, py, cx, cy, 1e-8, flip_u, flip_v, flip_w, True, False,
+                 params=g.oracle_params())
+    bm = g.binmap()
+    assert np.array_equal(bm["iu0"], o.iu0) and np.array_equal(bm["iv0"], o.iv0) and np.array_equal(bm["flip"], o.flip)
+    g.close()
