@@ -244,7 +244,8 @@ def main():
                 "active_vis_per_band": int(g.nactive), "image": [nx, ny], "epsilon": args.epsilon,
                 "grid": [info["nu"], info["nv"]], "occupied_rows": info["occ_rows"], "w_planes": info["nplanes"],
                 "kernel_support": info["W"], "plane_transform": ("own row FFT" if info["fft_mode"] & 1 else "rocFFT rows") +
-                (" + fused second axis" if info["fft_mode"] & 2 else " + rocFFT second axis"),
+                (" + fused second axis" if info["fft_mode"] & 2 else
+                 (" + own second axis (unfused)" if info["fft_mode"] & 4 else " + rocFFT second axis")),
                 "sigma": info["sigma"], "parallelism": f"band-per-gpu x{world}" + (f" + 1 RCCL sum-to-root of the image per {reduce_every} applies" if world > 1 else ""),
                 "plan_seconds": round(t_plan, 2),
             },

@@ -103,8 +103,9 @@ typedef struct pfbhip_gridder_info {
     int32_t occ_rows;      /* rows of the uv-plane that hold visibilities (only these are cleared / transformed) */
     double wcenter, whalf;
     size_t device_bytes;   /* device memory held by the handle                */
-    /* plane transform: bit 0 = hand-written row FFT on the first axis (else rocFFT), bit 1 = second axis fused
-     * with pad / crop / w-screen (else rocFFT + separate kernels); both need sizes {1,3,5} x 2^a in 1024..16384 */
+    /* plane transform: bit 0 = hand-written row FFT on the first axis (else rocFFT); bit 1 = second axis fused
+     * with pad / crop / w-screen (sizes {1,3,5} x 2^a in 1024..16384); bit 2 = second axis on the hand-written
+     * FFT with separate pad / crop kernels (the doubled sizes 20480, 24576); neither bit 1 nor 2: rocFFT */
     int32_t fft_mode;
     int32_t screen_poly;   /* coefficients of the n-1 polynomial of the fused w-screen (0: closed form) */
 } pfbhip_gridder_info;

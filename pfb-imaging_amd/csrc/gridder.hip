@@ -568,9 +568,13 @@ struct pfbhip_gridder {
     // ny row transforms of B (length nu)
     void fft_rows_B(bool forward)
     {
-        void *buf[1] = {d_gridB.p};
         timer.begin(2);
-        PFB_ROCFFT(rocfft_execute(forward ? fftB_fwd : fftB_bwd, buf, nullptr, fft_info));
+        if (rowfft_u.ok) {  // unfused second axis on the hand-written FFT (doubled shapes, PFBHIP_FUSED_FFT=0 + PFBHIP_ROWFFT=1)
+            rowfft_plain(rowfft_u.pl, d_gridB.p, int(prm.ny), !forward, stream);
+        } else {
+            void *buf[1] = {d_gridB.p};
+            PFB_ROCFFT(rocfft_execute(forward ? fftB_fwd : fftB_bwd, buf, nullptr, fft_info));
+        }
         timer.end();
     }
 
@@ -1235,8 +1239,15 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     // force the rocFFT paths (used by the tests to keep both alive).
     const char *fenv = std::getenv("PFBHIP_FUSED_FFT");
     const char *renv = std::getenv("PFBHIP_ROWFFT");
-    g->fused = !(fenv != nullptr && fenv[0] == '0') && g->rowfft_u.init(info.nu);
-    if (!(renv != nullptr && renv[0] == '0')) (void)g->rowfft_v.init(info.nv);
+    const bool own_rows = !(renv != nullptr && renv[0] == '0');
+    const bool want_fused = !(fenv != nullptr && fenv[0] == '0');
+    if (own_rows || want_fused) (void)g->rowfft_u.init(info.nu);
+    // Doubled shapes (20480, 24576 points) run the plain row kernel on both axes but keep the separate pad / crop
+    // kernels: their fused forms carry two transforms' worth of load / epilogue state and spill ~250 VGPRs
+    // (measured on the C5-size grid: 336 ms against ~310 ms unfused for the second axis).
+    g->fused = want_fused && g->rowfft_u.ok && !g->rowfft_u.pl.doubled;
+    if (!own_rows && !g->fused) g->rowfft_u.release();
+    if (own_rows) (void)g->rowfft_v.init(info.nv);
     if (g->fused) {
         FusedGeom &fg = g->fgeom;
         fg.nx = int(prm.nx);
@@ -1250,7 +1261,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         if (prm.do_wgridding) fused_geom_fit(fg);
         if (prm.verbosity > 0) fprintf(stderr, "[pfbhip] fused w-screen: n-1 polynomial with %d coefficients\n", fg.npoly);
     }
-    info.fft_mode = (g->rowfft_v.ok ? 1 : 0) | (g->fused ? 2 : 0);
+    info.fft_mode = (g->rowfft_v.ok ? 1 : 0) | (g->fused ? 2 : 0) | ((!g->fused && g->rowfft_u.ok) ? 4 : 0);
     info.screen_poly = g->fused ? g->fgeom.npoly : 0;
     g->bstride = size_t(prm.ny) * size_t(info.nu);
     g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
@@ -1311,7 +1322,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         g->occ_rows += sp.nrows;
         g->spans.push_back(sp);
     }
-    if (!g->fused) {  // the hand-written fused row FFT replaces the second-axis rocFFT pass when nu is supported
+    if (!g->fused && !g->rowfft_u.ok) {  // second axis on rocFFT only if the hand-written FFT does not take nu
         g->fftB_fwd = make_rows(info.nu, prm.ny, true);
         g->fftB_bwd = make_rows(info.nu, prm.ny, false);
     }

@@ -51,14 +51,21 @@ bool RowFFT::init(int64_t N)
 {
     release();
     if (!rowfft_make_plan(N, &pl)) return false;
-    std::vector<double2> tw(static_cast<size_t>(N), make_double2(0.0, 0.0));
     const long double pi = 3.141592653589793238462643383279502884L;
-    for (int64_t k = 0; k < N; ++k) {
-        long double a = -2.0L * pi * (long double)k / (long double)N;
+    // plain shapes: exp(-2 pi i k / N), k < N.  Doubled shapes: the N1-point table, then exp(-2 pi i k / N), k < N1.
+    const int64_t n1 = pl.doubled ? N / 2 : N;
+    std::vector<double2> tw(static_cast<size_t>(pl.doubled ? 2 * n1 : n1), make_double2(0.0, 0.0));
+    for (int64_t k = 0; k < n1; ++k) {
+        long double a = -2.0L * pi * (long double)k / (long double)n1;
         tw[size_t(k)] = make_double2(double(cosl(a)), double(sinl(a)));
     }
-    PFB_HIP(hipMalloc(reinterpret_cast<void **>(&d_tw), size_t(N) * sizeof(double2)));
-    PFB_HIP(hipMemcpy(d_tw, tw.data(), size_t(N) * sizeof(double2), hipMemcpyHostToDevice));
+    if (pl.doubled)
+        for (int64_t k = 0; k < n1; ++k) {
+            long double a = -2.0L * pi * (long double)k / (long double)N;
+            tw[size_t(n1 + k)] = make_double2(double(cosl(a)), double(sinl(a)));
+        }
+    PFB_HIP(hipMalloc(reinterpret_cast<void **>(&d_tw), tw.size() * sizeof(double2)));
+    PFB_HIP(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice));
     pl.twiddle = d_tw;
     ok = true;
     return true;
@@ -89,6 +96,13 @@ void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inver
         else launch_plain<RfShape<L, K>, false>(pl, data_dev, nrows, stream);        \
         break;
         RF_FOR_SHAPES(RF_X)
+#undef RF_X
+#define RF_X(L, K)                                                                                 \
+    case 2 * (L << K):                                                                             \
+        if (inverse) launch_plain<RfShape2<RfShape<L, K>>, true>(pl, data_dev, nrows, stream);     \
+        else launch_plain<RfShape2<RfShape<L, K>>, false>(pl, data_dev, nrows, stream);            \
+        break;
+        RF_FOR_SHAPES2(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);
     }
@@ -165,10 +179,10 @@ __device__ __forceinline__ int fg_ix(const FusedGeom &g, int u)
 // byte load in front of every row load doubles the latency of the load phase.
 struct OccLoad {
     const double2 *row;
-    uint32_t mask;
+    uint64_t mask;
     __device__ __forceinline__ double2 operator()(int u, int slot) const
     {
-        return ((mask >> slot) & 1u) ? row[u] : make_double2(0.0, 0.0);
+        return ((mask >> slot) & 1ull) ? row[u] : make_double2(0.0, 0.0);
     }
 };
 
@@ -183,8 +197,8 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
     double *acc = rf_lds + S::LDS_BYTES / sizeof(double);
     const int y = blockIdx.x;
     double *arow = accT + size_t(y) * g.nx;
-    uint32_t mask = 0;
-    rf_for_each_load<S>(int(threadIdx.x), [&](int u, int slot) { mask |= (occ[u >> 5] ? 1u : 0u) << slot; });
+    uint64_t mask = 0;
+    rf_for_each_load<S>(int(threadIdx.x), [&](int u, int slot) { mask |= (occ[u >> 5] ? 1ull : 0ull) << slot; });
     for (int k = 0; k < planes.kp; ++k) {
         OccLoad ld{B + size_t(k) * bstride + size_t(y) * g.nu, mask};
         double re[S::E], im[S::E];
@@ -375,12 +389,12 @@ void fused_geom_fit(FusedGeom &g)
 
 // The fused kernels transpose one component at a time (N doubles of LDS), which leaves room for the
 // workgroup's image row (nx doubles) when (N + nx) * 8 <= 160 KiB.
-static bool fused_row_fits(int N, int nx)
+static bool fused_row_fits(int lds_bytes, int nx)
 {
     // PFBHIP_FUSED_LDSROW=0 forces the read-modify-write form (what large grids use) so that tests reach it
     const char *env = std::getenv("PFBHIP_FUSED_LDSROW");
     if (env != nullptr && env[0] == '0') return false;
-    return (size_t(N) + size_t(nx)) * sizeof(double) <= 160 * 1024;
+    return size_t(lds_bytes) + size_t(nx) * sizeof(double) <= 160 * 1024;
 }
 
 template <class S>
@@ -390,7 +404,7 @@ static void launch_crop(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t 
 {
     static bool attr = false;
     rf_allow_lds(&k_fused_fft_crop<S>, &attr);
-    const bool row = fused_row_fits(S::N, g.nx) && planes.kp > 1;
+    const bool row = fused_row_fits(S::LDS_BYTES, g.nx) && planes.kp > 1;
     const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
     hipLaunchKernelGGL(k_fused_fft_crop<S>, dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
                        bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin);
@@ -403,7 +417,7 @@ static void launch_pad(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *
 {
     static bool attr = false;
     rf_allow_lds(&k_fused_pad_fft<S>, &attr);
-    const bool row = fused_row_fits(S::N, g.nx) && planes.kp > 1;
+    const bool row = fused_row_fits(S::LDS_BYTES, g.nx) && planes.kp > 1;
     const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
     hipLaunchKernelGGL(k_fused_pad_fft<S>, dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
                        prep, planes, do_w, row ? 1 : 0, B_dev, bstride);
@@ -419,6 +433,13 @@ void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev,
         break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X
+#define RF_X(L, K)                                                                                                        \
+    case 2 * (L << K):                                                                                                    \
+        launch_crop<RfShape2<RfShape<L, K, false>>>(f.pl, g, occ_dev, B_dev, bstride, planes, do_w, first, accT_dev, fin, \
+                                                    stream);                                                              \
+        break;
+        RF_FOR_SHAPES2(RF_X)
+#undef RF_X
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", f.pl.N);
     }
     PFB_HIP(hipGetLastError());
@@ -433,6 +454,12 @@ void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, 
         launch_pad<RfShape<L, K, false>>(f.pl, g, occ_dev, dcT_dev, prep, planes, do_w, B_dev, bstride, stream); \
         break;
         RF_FOR_SHAPES(RF_X)
+#undef RF_X
+#define RF_X(L, K)                                                                                                      \
+    case 2 * (L << K):                                                                                                  \
+        launch_pad<RfShape2<RfShape<L, K, false>>>(f.pl, g, occ_dev, dcT_dev, prep, planes, do_w, B_dev, bstride, stream); \
+        break;
+        RF_FOR_SHAPES2(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", f.pl.N);
     }

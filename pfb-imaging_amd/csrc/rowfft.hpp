@@ -40,9 +40,18 @@ namespace pfbhip {
 #endif
 constexpr int rf_elems(int N) { return (N >= RF_E32_MINN && N <= RF_E32_MAXN) ? 32 : 16; }
 
+// Doubled shapes N = 2 N1 (N1 = LEAD * 2^K from this list): one workgroup runs the N1-point transforms of the
+// even and the odd samples one after the other and combines them (X[k] = E[k] + w^k O[k], X[k + N1] = E[k] -
+// w^k O[k]); E waits in registers / compiler-managed scratch meanwhile.  Extends the range to 20480 and 24576
+// points (uv-grids of 16k^2 images).
+#define RF_FOR_SHAPES2(X) X(5, 11) X(3, 12)
+
 struct RowFFTPlan {
     int N = 0, T = 0, lead = 0, K = 0;
-    const double2 *twiddle = nullptr;  // device table exp(-2 pi i k / N), k < N (filled by the owner of the plan)
+    int doubled = 0;                   // 1: N = 2 N1, run as two N1-point transforms + combine
+    // device table (filled by the owner of the plan): exp(-2 pi i k / N), k < N; doubled shapes: the N1-point table
+    // followed by exp(-2 pi i k / N), k < N1
+    const double2 *twiddle = nullptr;
 };
 
 // radix of pass p of the power-of-two part 2^K (after the optional leading radix-3/5 pass)
@@ -68,6 +77,17 @@ inline bool rowfft_make_plan(int64_t N, RowFFTPlan *p)
     }
     RF_FOR_SHAPES(RF_X)
 #undef RF_X
+#define RF_X(L, KK)                          \
+    if (N == 2 * (int64_t(L) << KK)) {       \
+        p->N = int(N);                       \
+        p->T = int(N / 2) / rf_elems(int(N / 2)); \
+        p->lead = L;                         \
+        p->K = KK + 1;                       \
+        p->doubled = 1;                      \
+        return true;                         \
+    }
+    RF_FOR_SHAPES2(RF_X)
+#undef RF_X
     return false;
 }
 
@@ -78,6 +98,11 @@ inline int64_t rowfft_size_at_least(double x)
 #define RF_X(L, KK)                                                       \
     if (double(int64_t(L) << KK) >= x - 1e-9 && (best == 0 || (int64_t(L) << KK) < best)) best = int64_t(L) << KK;
     RF_FOR_SHAPES(RF_X)
+#undef RF_X
+#define RF_X(L, KK)                                                               \
+    if (double(2 * (int64_t(L) << KK)) >= x - 1e-9 && (best == 0 || 2 * (int64_t(L) << KK) < best)) \
+        best = 2 * (int64_t(L) << KK);
+    RF_FOR_SHAPES2(RF_X)
 #undef RF_X
     return best;
 }
@@ -386,6 +411,8 @@ template <int LEAD_, int K_, bool ALLOW_DUAL = true, int E_ = 0>
 struct RfShape {
     static constexpr int LEAD = LEAD_, K = K_;
     static constexpr int N = LEAD_ << K_, E = E_ > 0 ? E_ : rf_elems(N), T = N / E;
+    static constexpr bool DOUBLED = false;
+    static constexpr int NSLOT = LEAD_ > 1 ? ((E + LEAD_ - 1) / LEAD_) * LEAD_ : E;  // load-functor slots per row
     static constexpr int NP = rf_npass(K_);
     static constexpr int RLAST = rf_radix(K_, NP - 1);
     // E = 32 shapes run two workgroups per CU and therefore transpose one component at a time
@@ -400,6 +427,24 @@ struct RfShape {
     static constexpr int WAVES_PER_SIMD = (WG_PER_CU * ((T + 63) / 64) + 3) / 4;  // register budget = 512 / this
     // position of the value left in slot e after the last pass
     static __device__ __forceinline__ int out_pos(int t, int e) { return t + rf_last_slot(RLAST, E, e) * T; }
+};
+
+// Doubled shape over S1 (see RF_FOR_SHAPES2): 2 S1::E values per thread, the second half at positions + N1.
+template <class S1_>
+struct RfShape2 {
+    using S1 = S1_;
+    static constexpr bool DOUBLED = true;
+    static constexpr int LEAD = S1::LEAD, K = S1::K + 1;
+    static constexpr int N = 2 * S1::N, E = 2 * S1::E, T = S1::T;
+    static constexpr int NSLOT = 2 * S1::NSLOT;
+    static constexpr bool DUAL = S1::DUAL;
+    static constexpr int LDS_BYTES = S1::LDS_BYTES;
+    static constexpr int WG_PER_CU = 1;
+    static constexpr int WAVES_PER_SIMD = ((T + 63) / 64 + 3) / 4;
+    static __device__ __forceinline__ int out_pos(int t, int e)
+    {
+        return e < S1::E ? S1::out_pos(t, e) : S1::N + S1::out_pos(t, e - S1::E);
+    }
 };
 
 // Passes P.. of the power-of-two part; w1 holds the (already requested) twiddles of pass P.  The
@@ -432,6 +477,28 @@ template <class S, class Load>
 __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, Load &ld, bool inverse, double *lds,
                                                int &t_out, double (&re)[S::E], double (&im)[S::E])
 {
+    if constexpr (S::DOUBLED) {
+        using S1 = typename S::S1;
+        double er[S1::E], ei[S1::E], orr[S1::E], oi[S1::E];
+        auto ld_even = [&](int pos, int slot) { return ld(2 * pos, slot); };
+        auto ld_odd = [&](int pos, int slot) { return ld(2 * pos + 1, slot + S1::NSLOT); };
+        int t;
+        rf_row_compute<S1>(tw, ld_even, inverse, lds, t, er, ei);
+        rf_row_compute<S1>(tw, ld_odd, inverse, lds, t, orr, oi);  // er / ei wait in registers or scratch
+        rf_opaque(t);
+        const double2 *__restrict__ tw2 = tw + S1::N;  // exp(-2 pi i k / N), k < N1
+#pragma unroll
+        for (int e = 0; e < S1::E; ++e) {
+            const double2 w = tw2[S1::out_pos(t, e)];
+            const double tr = orr[e] * w.x - oi[e] * w.y, ti = orr[e] * w.y + oi[e] * w.x;
+            re[e] = er[e] + tr;
+            im[e] = ei[e] + ti;
+            re[e + S1::E] = er[e] - tr;
+            im[e + S1::E] = ei[e] - ti;
+        }
+        t_out = t;
+        return;
+    } else {
     int t = threadIdx.x;
     // Opaque to the optimiser: otherwise every pass's (row-invariant) LDS and global addresses are
     // hoisted out of the caller's loops and kept live -- hundreds of VGPRs of loop invariants.
@@ -451,14 +518,19 @@ __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, L
         }
     }
     rf_passes<S, 0, S::LEAD>(re, im, t, tw, lds, w0);
+    }
 }
 
 // Calls f(pos, slot) for every element the load functor of rf_row_compute<S> will be asked for by
-// thread t, in the same order and with the same compile-time slot numbers (< 32).
+// thread t, in the same order and with the same compile-time slot numbers (< 64).
 template <class S, class F>
 __device__ __forceinline__ void rf_for_each_load(int t, F &&f)
 {
-    if constexpr (S::LEAD > 1) {
+    if constexpr (S::DOUBLED) {
+        using S1 = typename S::S1;
+        rf_for_each_load<S1>(t, [&](int pos, int slot) { f(2 * pos, slot); });
+        rf_for_each_load<S1>(t, [&](int pos, int slot) { f(2 * pos + 1, slot + S1::NSLOT); });
+    } else if constexpr (S::LEAD > 1) {
         constexpr int M = S::LEAD, IT = (S::E + M - 1) / M, nbf = S::N / M;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {

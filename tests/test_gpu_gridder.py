@@ -332,7 +332,7 @@ def test_handwritten_row_fft_matches_numpy():
     from pfb_imaging_amd._lib import check, cint, i64, lib, ptr
 
     rng = np.random.default_rng(0)
-    for n in (1024, 1280, 1536, 2048, 5120, 6144, 8192, 10240, 12288, 16384):
+    for n in (1024, 1280, 1536, 2048, 5120, 6144, 8192, 10240, 12288, 16384, 20480, 24576):
         a = rng.standard_normal((5, n)) + 1j * rng.standard_normal((5, n))
         for inverse in (0, 1):
             b = a.copy()
