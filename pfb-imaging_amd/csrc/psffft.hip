@@ -12,7 +12,11 @@
 
 namespace pfbhip {
 
-#define PSF_FOR_SHAPES(X) X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14)
+// y axis (passes 1 and 3): every plain shape of the row FFT.  x axis (pass 2: forward, multiply, inverse on the same
+// row): powers of two chain the two transforms in registers; lengths with a leading radix-3/5 pass hand the row
+// over through LDS (both components: N * 16 bytes <= 160 KiB, i.e. N <= 10240).
+#define PSF_FOR_SHAPES_Y(X) RF_FOR_SHAPES(X)
+#define PSF_FOR_SHAPES_X(X) X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14) X(3, 9) X(3, 10) X(3, 11) X(5, 8) X(5, 9) X(5, 10) X(5, 11)
 // (32 complex per thread at 16384 points -- 512 threads, 256 VGPRs -- was tried against the 1024-thread /
 // 128-VGPR layout and its 35-120 spilled registers in these fused kernels: it spills more.)
 template <int L, int K>
@@ -43,6 +47,9 @@ static void transpose_any(const T *in, int64_t rows, int64_t cols, size_t ld_in,
                        in, int(rows), int(cols), ld_in, out, ld_out);
     PFB_HIP(hipGetLastError());
 }
+
+template <class S>
+__device__ __forceinline__ int rf_neg_index(int k) { return k == 0 ? 0 : S::N - k; }  // (N - k) mod N
 
 // ---- pass 1: rows of beam * x, zero-padded to nyp, forward along y, half spectrum kept --------------
 // Two real rows share one complex transform: z = a + i b, A[k] = (Z[k] + conj Z[N-k]) / 2,
@@ -84,13 +91,13 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_rows_fwd(const 
     for (int e = 0; e < S::E; ++e) rf_lds[rf_swz(S::out_pos(t, e))] = re[e];
     rf_barrier();
 #pragma unroll
-    for (int e = 0; e < S::E; ++e) pre[e] = rf_lds[rf_swz((S::N - S::out_pos(t, e)) & (S::N - 1))];
+    for (int e = 0; e < S::E; ++e) pre[e] = rf_lds[rf_swz(rf_neg_index<S>(S::out_pos(t, e)))];
     rf_barrier();
 #pragma unroll
     for (int e = 0; e < S::E; ++e) rf_lds[rf_swz(S::out_pos(t, e))] = im[e];
     rf_barrier();
 #pragma unroll
-    for (int e = 0; e < S::E; ++e) pim[e] = rf_lds[rf_swz((S::N - S::out_pos(t, e)) & (S::N - 1))];
+    for (int e = 0; e < S::E; ++e) pim[e] = rf_lds[rf_swz(rf_neg_index<S>(S::out_pos(t, e)))];
     double2 *rowa = t1 + r0 * ld1, *rowb = rowa + ld1;
 #pragma unroll
     for (int e = 0; e < S::E; ++e) {
@@ -110,6 +117,13 @@ struct PsfColLoad {
     {
         return p < nx ? row[p] : make_double2(0.0, 0.0);
     }
+};
+
+struct PsfLdsLoad {
+    static constexpr bool FROM_LDS = true;
+    const double *l;
+    int N;
+    __device__ __forceinline__ double2 operator()(int p, int) const { return make_double2(l[p], l[N + p]); }
 };
 
 // mode 0: psf, 1: psf + shift, 2: 1 / (psf + shift); norm = 1 / (nxp nyp) folded in
@@ -165,12 +179,27 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_cols(const doub
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    const double2 w0[S::E / rf_radix(S::K, 0)] = {};
     // a second opaque copy of the thread index: otherwise the LDS / twiddle addresses of the second
     // transform are common subexpressions of the first and stay live through it (130 spilled VGPRs)
     int tb = t;
     rf_opaque(tb);
-    rf_passes<S, 0, 1>(re2, im2, tb, tw, rf_lds, w0);
+    if constexpr (S::LEAD == 1) {
+        const double2 w0[S::E / rf_radix(S::K, 0)] = {};
+        rf_passes<S, 0, 1>(re2, im2, tb, tw, rf_lds, w0);
+    } else {
+        // the leading radix-3/5 pass of the second transform needs other threads' values: hand the row over through LDS
+        static_assert(S::DUAL, "the LDS hand-over needs both components in LDS");
+#pragma unroll
+        for (int e = 0; e < S::E; ++e) {  // re2 / im2 are in natural slot order: slot e <-> position tb + e T
+            rf_lds[tb + e * S::T] = re2[e];
+            rf_lds[S::N + tb + e * S::T] = im2[e];
+        }
+        rf_barrier();
+        PsfLdsLoad ll{rf_lds, S::N};
+        int tc;
+        rf_row_compute<S>(tw, ll, false, rf_lds, tc, re2, im2);
+        tb = tc;
+    }
 #pragma unroll
     for (int e = 0; e < S::E; ++e) {
         const int p = S::out_pos(tb, e);
@@ -242,7 +271,8 @@ bool PsfFFT::init(int64_t nx_, int64_t ny_, int64_t nxp_, int64_t nyp_)
     const char *env = std::getenv("PFBHIP_PSF_ROWFFT");
     if (env != nullptr && env[0] == '0') return false;
     RowFFTPlan a, b;
-    if (!rowfft_make_plan(nxp_, &a) || !rowfft_make_plan(nyp_, &b) || a.lead != 1 || b.lead != 1) return false;
+    if (!rowfft_make_plan(nxp_, &a) || !rowfft_make_plan(nyp_, &b) || a.doubled || b.doubled) return false;
+    if (a.lead != 1 && nxp_ * 16 > 160 * 1024) return false;  // pass 2 hands rows with a radix-3/5 lead over through LDS
     if (nx_ > nxp_ || ny_ > nyp_) return false;
     nx = nx_;
     ny = ny_;
@@ -299,7 +329,7 @@ void PsfFFT::apply(const double *x_dev, const double *beam_dev, const double *ps
     switch (nyp) {
 #define RF_X(L, K) \
     case (L << K): launch_rows_fwd<PsfShape<L, K>>(*this, x_dev, beam_dev, st); break;
-        PSF_FOR_SHAPES(RF_X)
+        PSF_FOR_SHAPES_Y(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nyp);
     }
@@ -308,7 +338,7 @@ void PsfFFT::apply(const double *x_dev, const double *beam_dev, const double *ps
     switch (nxp) {
 #define RF_X(L, K) \
     case (L << K): launch_cols<PsfShape<L, K>>(*this, psfT_dev, is_complex, mode, shift, st); break;
-        PSF_FOR_SHAPES(RF_X)
+        PSF_FOR_SHAPES_X(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nxp);
     }
@@ -317,7 +347,7 @@ void PsfFFT::apply(const double *x_dev, const double *beam_dev, const double *ps
     switch (nyp) {
 #define RF_X(L, K) \
     case (L << K): launch_rows_inv<PsfShape<L, K>>(*this, beam_dev, x_dev, scale, eta, accumulate, out_dev, st); break;
-        PSF_FOR_SHAPES(RF_X)
+        PSF_FOR_SHAPES_Y(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nyp);
     }

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace pfbhip {
 
@@ -348,6 +349,13 @@ __host__ __device__ constexpr int rf_last_slot(int R, int E, int e)
     return i + d * IT;
 }
 
+// A load functor that reads the transpose buffer itself (static constexpr bool FROM_LDS = true) needs all of the
+// workgroup's loads finished before the first transpose write: the leading odd pass then gathers its inputs first.
+template <class Load, class = void>
+struct rf_load_from_lds : std::false_type {};
+template <class Load>
+struct rf_load_from_lds<Load, std::void_t<decltype(Load::FROM_LDS)>> : std::bool_constant<Load::FROM_LDS> {};
+
 // Leading odd pass (radix M = 3 or 5, Ns = 1): N/M butterflies, ceil(E/M) per thread, inputs read
 // straight from the load functor, outputs written straight into the LDS transpose.
 template <int M, int E, bool DUAL, class Load>
@@ -355,9 +363,20 @@ __device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], i
                                              bool inverse, double *lds)
 {
     constexpr int IT = (E + M - 1) / M;
+    constexpr bool PRE = rf_load_from_lds<Load>::value;
     const int nbf = N / M;
     double *l2 = lds + N;
     double oim[DUAL ? 1 : IT * M];
+    double2 vin[PRE ? IT * M : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int j = t + i * T;
+#pragma unroll
+            for (int q = 0; q < M; ++q) vin[i * M + q] = j < nbf ? ld(j + q * nbf, i * M + q) : make_double2(0.0, 0.0);
+        }
+        rf_barrier();
+    }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int j = t + i * T;
@@ -365,7 +384,9 @@ __device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], i
         if (j < nbf) {
 #pragma unroll
             for (int q = 0; q < M; ++q) {
-                double2 x = ld(j + q * nbf, i * M + q);
+                double2 x;
+                if constexpr (PRE) x = vin[i * M + q];
+                else x = ld(j + q * nbf, i * M + q);
                 v[q] = inverse ? make_double2(x.y, x.x) : x;
             }
             dft<M>(v);

@@ -271,14 +271,15 @@ def test_hessian_equals_psf_convolution(center_offset):
     assert np.allclose(1 + diff, 1)
 
 
-@pytest.mark.parametrize("is_complex,nx", [(False, 600), (True, 600), (False, 601)])
-def test_psfconv_rowfft_pipeline(is_complex, nx, monkeypatch):
+@pytest.mark.parametrize("is_complex,nx,nxp,nyp", [(False, 600, 2048, 1024), (True, 600, 2048, 1024), (False, 601, 2048, 1024),
+                                                    (True, 600, 1280, 1536), (False, 602, 3072, 5120)])
+def test_psfconv_rowfft_pipeline(is_complex, nx, nxp, nyp, monkeypatch):
     """Power-of-two padded sizes take the three-pass row-FFT pipeline (csrc/psffft.hip); every mode, beam,
     eta and accumulate against numpy, and against the rocFFT fallback (PFBHIP_PSF_ROWFFT=0)."""
     from pfb_imaging_amd.psfconv import PsfConv
 
     rng = np.random.default_rng(11)
-    ny, nxp, nyp = 520, 2048, 1024  # (odd nx: the last row has no partner in the paired transforms)
+    ny = 520  # (odd nx: the last row has no partner in the paired transforms; 1280 / 1536 / 3072 / 5120: radix-3/5 leads)
     psf = rng.standard_normal((nxp, nyp))
     psfhat = np.fft.rfft2(np.fft.ifftshift(psf))
     ph = psfhat if is_complex else 1.0 + np.abs(psfhat) / np.abs(psfhat).max()
