@@ -104,7 +104,7 @@ typedef struct pfbhip_gridder_info {
     double wcenter, whalf;
     size_t device_bytes;   /* device memory held by the handle                */
     /* plane transform: bit 0 = hand-written row FFT on the first axis (else rocFFT); bit 1 = second axis fused
-     * with pad / crop / w-screen (sizes {1,3,5} x 2^a in 1024..16384); bit 2 = second axis on the hand-written
+     * with pad / crop / w-screen (sizes {1,3,5,7,9,15} x 2^a in 1024..16384); bit 2 = second axis on the hand-written
      * FFT with separate pad / crop kernels (the doubled sizes 20480, 24576); neither bit 1 nor 2: rocFFT */
     int32_t fft_mode;
     int32_t screen_poly;   /* coefficients of the n-1 polynomial of the fused w-screen (0: closed form) */
@@ -172,7 +172,7 @@ int pfbhip_r2c_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1,
 int pfbhip_c2r_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1 /* lastsize */, double *out_host);
 
 /* Hand-written batched row FFT (the second-axis pass of the plane transform), exposed for tests and
- * benchmarks: in-place transform of (nrows, n) complex doubles, n = m 2^a (m in 1,3,5), 1024 <= n <= 16384.
+ * benchmarks: in-place transform of (nrows, n) complex doubles, n = m 2^a (m in 1,3,5,7,9,15), 1024 <= n <= 16384, or 20480 / 24576.
  * ms_out (may be NULL) receives the device time per transform when reps > 1. */
 int pfbhip_debug_rowfft(double *data_host, int64_t n, int64_t nrows, int inverse, int reps, double *ms_out);
 

@@ -24,11 +24,12 @@
 namespace pfbhip {
 
 // Supported row lengths: N = LEAD * 2^K with (LEAD, K) in RF_FOR_SHAPES, i.e. 1024 <= N <= 16384 of
-// the forms 2^a, 3*2^a, 5*2^a.  Every shape is its own kernel instantiation: the pass sequence, N and
+// the forms {1, 3, 5, 7, 9, 15} * 2^a.  Every shape is its own kernel instantiation: the pass sequence, N and
 // T are compile-time constants (straight-line code; a run-time radix switch costs ~60 more VGPRs and
 // 35 % of the throughput).
-#define RF_FOR_SHAPES(X) \
-    X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14) X(3, 9) X(3, 10) X(3, 11) X(3, 12) X(5, 8) X(5, 9) X(5, 10) X(5, 11)
+#define RF_FOR_SHAPES(X)                                                                                              \
+    X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14) X(3, 9) X(3, 10) X(3, 11) X(3, 12) X(5, 8) X(5, 9) X(5, 10) X(5, 11) \
+    X(7, 8) X(7, 9) X(7, 10) X(7, 11) X(9, 7) X(9, 8) X(9, 9) X(9, 10) X(15, 7) X(15, 8) X(15, 9) X(15, 10)
 
 // complex elements per thread: 32 (T = N/32 threads per row) where that leaves room for TWO rows per
 // CU (registers: 10 waves of <= 168 VGPRs; LDS: 2 x N doubles), so that one row's butterflies overlap
@@ -59,9 +60,9 @@ struct RowFFTPlan {
 constexpr int rf_npass(int K) { return (K + 3) / 4; }
 constexpr int rf_radix(int K, int p)
 {
-    // 8: 16 16 | 9: 16 8 4 | 10: 16 16 4 | 11: 16 16 8 | 12: 16 16 16 | 13: 16 16 8 4 | 14: 16 16 16 4
+    // 7: 16 8 | 8: 16 16 | 9: 16 8 4 | 10: 16 16 4 | 11: 16 16 8 | 12: 16 16 16 | 13: 16 16 8 4 | 14: 16 16 16 4
     return p == 0 ? 16
-         : p == 1 ? (K == 9 ? 8 : 16)
+         : p == 1 ? (K == 9 || K == 7 ? 8 : 16)
          : p == 2 ? (K == 9 || K == 10 ? 4 : (K == 11 || K == 13 ? 8 : 16))
                   : 4;
 }
@@ -167,6 +168,78 @@ __device__ __forceinline__ void dft<5>(double2 (&v)[5])
     v[4] = csub(p1, q1);
     v[2] = cadd(p2, q2);
     v[3] = csub(p2, q2);
+}
+
+template <>
+__device__ __forceinline__ void dft<7>(double2 (&v)[7])
+{
+    const double c1 = 0.62348980185873353053, c2 = -0.22252093395631440429, c3 = -0.90096886790241912624;
+    const double s1 = 0.78183148246802980871, s2 = 0.97492791218182360702, s3 = 0.43388373911755812048;
+    const double2 a1 = cadd(v[1], v[6]), a2 = cadd(v[2], v[5]), a3 = cadd(v[3], v[4]);
+    const double2 b1 = csub(v[1], v[6]), b2 = csub(v[2], v[5]), b3 = csub(v[3], v[4]);
+    const double2 x0 = v[0];
+    // X_k = x0 + sum_j cos(2 pi j k / 7) a_j - i sum_j sin(2 pi j k / 7) b_j ; X_{7-k} with + i
+    const double2 p1 = make_double2(x0.x + c1 * a1.x + c2 * a2.x + c3 * a3.x, x0.y + c1 * a1.y + c2 * a2.y + c3 * a3.y);
+    const double2 p2 = make_double2(x0.x + c2 * a1.x + c3 * a2.x + c1 * a3.x, x0.y + c2 * a1.y + c3 * a2.y + c1 * a3.y);
+    const double2 p3 = make_double2(x0.x + c3 * a1.x + c1 * a2.x + c2 * a3.x, x0.y + c3 * a1.y + c1 * a2.y + c2 * a3.y);
+    const double2 q1 = mul_mi(make_double2(s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y));
+    const double2 q2 = mul_mi(make_double2(s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y));
+    const double2 q3 = mul_mi(make_double2(s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y));
+    v[0] = cadd(x0, cadd(a1, cadd(a2, a3)));
+    v[1] = cadd(p1, q1);
+    v[6] = csub(p1, q1);
+    v[2] = cadd(p2, q2);
+    v[5] = csub(p2, q2);
+    v[3] = cadd(p3, q3);
+    v[4] = csub(p3, q3);
+}
+
+template <>
+__device__ __forceinline__ void dft<9>(double2 (&v)[9])
+{
+    // n = 3 n1 + n2, k = k1 + 3 k2 : t[n2][k1] = DFT3_{n1} x[3 n1 + n2] * w9^(n2 k1) ; X[k1 + 3 k2] = DFT3_{n2} t[n2][k1]
+    const double2 w1 = make_double2(0.76604444311897803520, -0.64278760968653932632);   // exp(-2 pi i / 9)
+    const double2 w2 = make_double2(0.17364817766693034885, -0.98480775301220805937);   // ^2
+    const double2 w4 = make_double2(-0.93969262078590838405, -0.34202014332566873304);  // ^4
+    double2 t[3][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 3; ++n2) {
+        double2 u[3] = {v[n2], v[3 + n2], v[6 + n2]};
+        dft<3>(u);
+        t[n2][0] = u[0];
+        t[n2][1] = n2 == 0 ? u[1] : cmul(u[1], n2 == 1 ? w1 : w2);
+        t[n2][2] = n2 == 0 ? u[2] : cmul(u[2], n2 == 1 ? w2 : w4);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {
+        double2 u[3] = {t[0][k1], t[1][k1], t[2][k1]};
+        dft<3>(u);
+        v[k1] = u[0];
+        v[k1 + 3] = u[1];
+        v[k1 + 6] = u[2];
+    }
+}
+
+template <>
+__device__ __forceinline__ void dft<15>(double2 (&v)[15])
+{
+    // prime-factor 3 x 5 (no twiddles): input (5 n1 + 3 n2) mod 15, output (10 k1 + 6 k2) mod 15
+    double2 t[5][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) {
+        double2 u[3] = {v[(3 * n2) % 15], v[(5 + 3 * n2) % 15], v[(10 + 3 * n2) % 15]};
+        dft<3>(u);
+        t[n2][0] = u[0];
+        t[n2][1] = u[1];
+        t[n2][2] = u[2];
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {
+        double2 u[5] = {t[0][k1], t[1][k1], t[2][k1], t[3][k1], t[4][k1]};
+        dft<5>(u);
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) v[(10 * k1 + 6 * k2) % 15] = u[k2];
+    }
 }
 
 // exp(-2 pi i m / 16), m = 0..9 (m is a compile-time constant at every call site)

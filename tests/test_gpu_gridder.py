@@ -332,7 +332,8 @@ def test_handwritten_row_fft_matches_numpy():
     from pfb_imaging_amd._lib import check, cint, i64, lib, ptr
 
     rng = np.random.default_rng(0)
-    for n in (1024, 1280, 1536, 2048, 5120, 6144, 8192, 10240, 12288, 16384, 20480, 24576):
+    for n in (1024, 1152, 1280, 1536, 1792, 1920, 2048, 2304, 3584, 3840, 4608, 5120, 6144, 7168, 7680, 8192, 9216, 10240, 12288,
+              14336, 15360, 16384, 20480, 24576):
         a = rng.standard_normal((5, n)) + 1j * rng.standard_normal((5, n))
         for inverse in (0, 1):
             b = a.copy()
@@ -380,6 +381,8 @@ def test_fused_row_fft_path(monkeypatch):
     (1200, 1000, (0.0, 0.0), 8.0, 0.02),        # grid 1536 x 1280 (3 * 2^9, 5 * 2^8): leading radix-3 and -5 passes
     (1600, 840, (0.003, -0.002), 8.0, 0.05),     # grid 2048 x 1280 / 1024: rectangular, shifted phase centre
     (1024, 1636, (0.0, 0.001), 30.0, 0.5),       # grid 1280 x 2048: wide field, ES-kernel planes, psi_w correction
+    (1000, 1560, (0.0, 0.0), 8.0, 0.02),          # grid 1152 x 1920 (9 * 2^7, 15 * 2^7): radix-9 and radix-15 leads
+    (1540, 1000, (-0.002, 0.001), 8.0, 0.05),     # grid 1792 x 1152 (7 * 2^8, 9 * 2^7)
 ])
 def test_own_fft_shapes_vs_oracle(nx, ny, center, widen, zscale):
     """Rectangular images whose padded sizes take the hand-written row FFT on both axes (different
