@@ -16,7 +16,9 @@ namespace pfbhip {
 // row): powers of two chain the two transforms in registers; lengths with a leading radix-3/5 pass hand the row
 // over through LDS (both components: N * 16 bytes <= 160 KiB, i.e. N <= 10240).
 #define PSF_FOR_SHAPES_Y(X) RF_FOR_SHAPES(X)
-#define PSF_FOR_SHAPES_X(X) X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14) X(3, 9) X(3, 10) X(3, 11) X(5, 8) X(5, 9) X(5, 10) X(5, 11)
+#define PSF_FOR_SHAPES_X(X)                                                                                     \
+    X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14) X(3, 9) X(3, 10) X(3, 11) X(5, 8) X(5, 9) X(5, 10) X(5, 11) X(7, 8) \
+    X(7, 9) X(7, 10) X(9, 7) X(9, 8) X(9, 9) X(9, 10) X(15, 7) X(15, 8) X(15, 9)
 // (32 complex per thread at 16384 points -- 512 threads, 256 VGPRs -- was tried against the 1024-thread /
 // 128-VGPR layout and its 35-120 spilled registers in these fused kernels: it spills more.)
 template <int L, int K>

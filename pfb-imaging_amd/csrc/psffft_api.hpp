@@ -10,7 +10,7 @@
 //   3. the nx output rows, two per transform (Z = A + i B): Hermitian-extended inverse FFT along y, real and
 //      imaginary parts, crop, beam, scale, eta
 // Nothing outside the nx x nyo2 corner is ever stored: ~6 GB of traffic at 8192^2 / 16384^2 where the
-// padded r2c / c2r pipeline moves ~24 GB.  Padded sizes: ny_psf any plain row-FFT size ({1,3,5} x 2^a, 1024..16384);
+// padded r2c / c2r pipeline moves ~24 GB.  Padded sizes: ny_psf any plain row-FFT size ({1,3,5,7,9,15} x 2^a, 1024..16384);
 // nx_psf a power of two (the two transforms of pass 2 chain in registers) or {3,5} x 2^a <= 10240 (they hand the row
 // over through LDS).
 #pragma once

@@ -272,7 +272,8 @@ def test_hessian_equals_psf_convolution(center_offset):
 
 
 @pytest.mark.parametrize("is_complex,nx,nxp,nyp", [(False, 600, 2048, 1024), (True, 600, 2048, 1024), (False, 601, 2048, 1024),
-                                                    (True, 600, 1280, 1536), (False, 602, 3072, 5120)])
+                                                    (True, 600, 1280, 1536), (False, 602, 3072, 5120),
+                                                    (False, 600, 1792, 1152), (True, 600, 1920, 2304)])
 def test_psfconv_rowfft_pipeline(is_complex, nx, nxp, nyp, monkeypatch):
     """Power-of-two padded sizes take the three-pass row-FFT pipeline (csrc/psffft.hip); every mode, beam,
     eta and accumulate against numpy, and against the rocFFT fallback (PFBHIP_PSF_ROWFFT=0)."""
