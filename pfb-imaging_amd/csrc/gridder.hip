@@ -935,7 +935,9 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
                 //  diagonal walk always takes 16 steps of LDS atomics / reads).
                 // (x 1.2 on the rocFFT path: its measured table is for the large sizes only, and every distinct size
                 // costs 1-3 s of rocFFT plan building that the hand-written path does not have)
-                const double plane_cost = own ? 2.7e-11 * double(nu) * double(nv)
+                // (doubled row-FFT shapes, > 16384 points: unfused second axis, measured 3.7e-11 s per point on C5)
+                const double own_pt = (nu > 16384 || nv > 16384) ? 3.7e-11 : 2.7e-11;
+                const double plane_cost = own ? own_pt * double(nu) * double(nv)
                                               : 1.2 * (fft2d_seconds(nu, nv) + 3.0 * 16.0 * double(nu) * double(nv) / 5.0e12);
                 const double gridcost = nvis * double(std::min<int64_t>(touched, npl)) * 0.30e-9;
                 const double cost = double(npl) * plane_cost + gridcost;
