@@ -6,8 +6,9 @@
 //
 // Algorithm (published method: Arras et al. 2021, A&A 646 A58; ES kernel of Barnett et al. 2019):
 //   vis2dirty: weight + phase-shift + Hermitian-fold the visibilities into tile-sorted order;
-//              per w-plane: scatter with phi(u)phi(v)phi(w) (k_grid) -> backward FFT (rocFFT) ->
-//              crop, multiply by the w-screen exp(-2 pi i w_p (n-1+nshift)), accumulate Re;
+//              per w-plane: scatter with phi(u)phi(v)phi(w) (k_grid_mp) -> backward 2-D FFT as two pruned row
+//              passes (rowfft.hpp; rocFFT row plans for sizes it does not take) -> crop, multiply by the
+//              w-screen exp(-2 pi i w_p (n-1+nshift)), accumulate Re (fused into the second row pass);
 //              finally multiply by the correction image 1/(psi_l psi_m psi_n) [/n].
 //   dirty2vis: the exact adjoint, backwards.
 //   hessian:   dirty2vis then vis2dirty with the model visibilities kept on the device in
@@ -261,9 +262,9 @@ __global__ void k_corr_image(ImgGeom g, const double *cfu, const double *cfv, co
 // ---------------------------------------------------------------------------------------
 // pruned two-pass plane transform
 // ---------------------------------------------------------------------------------------
-// The 2-D FFT of a w-plane is done as two batched ROW transforms (rocFFT runs contiguous rows of
-// length <= 10240 at ~3.8 TB/s, strided columns at ~1 TB/s) with a transpose of our own in
-// between, and every pass is pruned to what the algorithm needs:
+// The 2-D FFT of a w-plane is done as two batched ROW transforms (contiguous rows run at ~4 TB/s, strided
+// columns at ~1 TB/s) with a transpose of our own in between, and every pass is pruned to what the
+// algorithm needs (here in the plan's own -- transposed -- coordinates, see pfbhip_gridder_create):
 //   A (nu, nv)  v contiguous : the uv-plane the scatter/gather kernels see.  Only the row blocks
 //                              that hold visibilities ("occupied", from the tile sort) are ever
 //                              cleared, transformed or transposed.
