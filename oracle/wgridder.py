@@ -99,14 +99,14 @@ def kernel_ft(v, W, beta):
 
 
 def kernel_poly_degree(W):
-    return min(max(W + 6, 12), 20)
+    return 12
 
 
 def kernel_poly_table(W, beta):
     """Piecewise-polynomial form of the kernel (the form the gridding kernels evaluate; the
     reference's gridder does the same with its own kernels): for tap a and sub-cell offset
-    f in [0,1), phi((a + 1 - W/2 - f) 2/W) ~= sum_k c[a,k] z^k, z = 2f - 1, degree
-    clamp(W+6, 12, 20), by Chebyshev interpolation in extended precision."""
+    f in [0,1), phi((a + 1 - W/2 - f) 2/W) ~= sum_k c[a,k] z^k, z = 2f - 1, degree 12,
+    by Chebyshev interpolation in extended precision."""
     D = kernel_poly_degree(W)
     n = D + 1
     ld = np.longdouble

@@ -35,9 +35,9 @@ int64_t grid_size(int64_t npix, double sigma);
 // Piecewise-polynomial form of the kernel for the device: for tap a (0 <= a < W) and sub-cell
 // offset f in [0,1) (first tap index i0 = floor(p + 1 - W/2), f = p + 1 - W/2 - i0)
 //     phi_a(f) = phi((a + 1 - W/2 - f) * 2 / W)  ~=  sum_k c[a][k] z^k ,  z = 2 f - 1 ,
-// degree D = clamp(W + 6, 12, 20) (Chebyshev interpolation, converted to monomials in long double).
+// degree D = 12 (Chebyshev interpolation, converted to monomials in long double).
 // Returns c as a row-major (W, D+1) table and the measured max abs error (kernel peak = 1).
-constexpr int kernel_poly_degree(int W) { return W + 6 > 20 ? 20 : (W + 6 < 12 ? 12 : W + 6); }
+constexpr int kernel_poly_degree(int) { return 12; }
 std::vector<double> kernel_poly_table(int W, double beta, double *max_err);
 
 }  // namespace pfbhip
