@@ -578,7 +578,9 @@ __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, L
         auto ld_odd = [&](int pos, int slot) { return ld(2 * pos + 1, slot + S1::NSLOT); };
         int t;
         rf_row_compute<S1>(tw, ld_even, inverse, lds, t, er, ei);
+        __builtin_amdgcn_sched_barrier(0);
         rf_row_compute<S1>(tw, ld_odd, inverse, lds, t, orr, oi);  // er / ei wait in registers or scratch
+        __builtin_amdgcn_sched_barrier(0);
         rf_opaque(t);
         const double2 *__restrict__ tw2 = tw + S1::N;  // exp(-2 pi i k / N), k < N1
 #pragma unroll
