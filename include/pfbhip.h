@@ -172,7 +172,7 @@ int pfbhip_r2c_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1,
 int pfbhip_c2r_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1 /* lastsize */, double *out_host);
 
 /* Hand-written batched row FFT (the second-axis pass of the plane transform), exposed for tests and
- * benchmarks: in-place transform of (nrows, n) complex doubles, n = m 2^a (m in 1,3,5,7,9,15), 1024 <= n <= 16384, or 20480 / 24576.
+ * benchmarks: in-place transform of (nrows, n) complex doubles, n = m 2^a (m in 1,3,5,7,9,15), 1024 <= n <= 16384, or 20480 / 24576 / 32768.
  * ms_out (may be NULL) receives the device time per transform when reps > 1. */
 int pfbhip_debug_rowfft(double *data_host, int64_t n, int64_t nrows, int inverse, int reps, double *ms_out);
 

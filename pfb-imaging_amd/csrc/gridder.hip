@@ -1245,7 +1245,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     const bool own_rows = !(renv != nullptr && renv[0] == '0');
     const bool want_fused = !(fenv != nullptr && fenv[0] == '0');
     if (own_rows || want_fused) (void)g->rowfft_u.init(info.nu);
-    // Doubled shapes (20480, 24576 points) run the plain row kernel on both axes but keep the separate pad / crop
+    // Doubled shapes (20480, 24576, 32768 points) run the plain row kernel on both axes but keep the separate pad / crop
     // kernels: their fused forms carry two transforms' worth of load / epilogue state and spill ~250 VGPRs
     // (measured on the C5-size grid: 336 ms against ~310 ms unfused for the second axis).
     g->fused = want_fused && g->rowfft_u.ok && !g->rowfft_u.pl.doubled;

@@ -44,9 +44,9 @@ constexpr int rf_elems(int N) { return (N >= RF_E32_MINN && N <= RF_E32_MAXN) ? 
 
 // Doubled shapes N = 2 N1 (N1 = LEAD * 2^K from this list): one workgroup runs the N1-point transforms of the
 // even and the odd samples one after the other and combines them (X[k] = E[k] + w^k O[k], X[k + N1] = E[k] -
-// w^k O[k]); E waits in registers / compiler-managed scratch meanwhile.  Extends the range to 20480 and 24576
+// w^k O[k]); E waits in registers / compiler-managed scratch meanwhile.  Extends the range to 20480, 24576 and 32768
 // points (uv-grids of 16k^2 images).
-#define RF_FOR_SHAPES2(X) X(5, 11) X(3, 12)
+#define RF_FOR_SHAPES2(X) X(5, 11) X(3, 12) X(1, 14)
 
 struct RowFFTPlan {
     int N = 0, T = 0, lead = 0, K = 0;

@@ -333,7 +333,7 @@ def test_handwritten_row_fft_matches_numpy():
 
     rng = np.random.default_rng(0)
     for n in (1024, 1152, 1280, 1536, 1792, 1920, 2048, 2304, 3584, 3840, 4608, 5120, 6144, 7168, 7680, 8192, 9216, 10240, 12288,
-              14336, 15360, 16384, 20480, 24576):
+              14336, 15360, 16384, 20480, 24576, 32768):
         a = rng.standard_normal((5, n)) + 1j * rng.standard_normal((5, n))
         for inverse in (0, 1):
             b = a.copy()
