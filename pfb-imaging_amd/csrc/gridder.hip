@@ -352,7 +352,7 @@ __global__ void k_b2a(ImgGeom g, const uint8_t *occ, const double2 *B, double2 *
 }
 
 // degrid side: B[y][wrap(x - nx/2, nu)] = dcT[y][x] * exp(+2 pi i w_p t), 0 elsewhere (whole B written once)
-__global__ void k_pad_screen_T(ImgGeom g, const double *dcT, int do_w, double wplane, double2 *B)
+__global__ void k_pad_screen_T(ImgGeom g, FusedGeom fg, const double *dcT, int do_w, double wplane, double2 *B)
 {
     int u = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y;
@@ -365,10 +365,10 @@ __global__ void k_pad_screen_T(ImgGeom g, const double *dcT, int do_w, double wp
     if (ix >= 0) {
         double val = dcT[size_t(y) * g.nx + ix];
         if (do_w) {
-            double ph = wplane * pixel_t(g, ix, y);
+            double ph = wplane * fg_t(fg, ix, y);  // the fused kernels' screen: polynomial n-1, folded Taylor sincos
             ph -= rint(ph);
             double s, c;
-            sincospi(2.0 * ph, &s, &c);
+            fg_sincos2pi(ph, s, c);
             out.x = val * c;
             out.y = val * s;
         } else {
@@ -379,7 +379,7 @@ __global__ void k_pad_screen_T(ImgGeom g, const double *dcT, int do_w, double wp
 }
 
 // grid side: accT[y][x] (+)= Re( B[y][wrap(x - nx/2, nu)] * exp(-2 pi i w_p t) )
-__global__ void k_crop_screen_T(ImgGeom g, const double2 *B, int do_w, double wplane, int first, double *accT)
+__global__ void k_crop_screen_T(ImgGeom g, FusedGeom fg, const double2 *B, int do_w, double wplane, int first, double *accT)
 {
     int ix = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y;
@@ -389,10 +389,10 @@ __global__ void k_crop_screen_T(ImgGeom g, const double2 *B, int do_w, double wp
     double2 v = B[size_t(y) * g.nu + u];
     double r;
     if (do_w) {
-        double ph = wplane * pixel_t(g, ix, y);
+        double ph = wplane * fg_t(fg, ix, y);
         ph -= rint(ph);
         double s, c;
-        sincospi(2.0 * ph, &s, &c);
+        fg_sincos2pi(ph, s, c);
         r = v.x * c + v.y * s;
     } else {
         r = v.x;
@@ -707,7 +707,7 @@ struct pfbhip_gridder {
                     fft_rows_B(false);
                     timer.begin(4);
                     hipLaunchKernelGGL(k_crop_screen_T, dim3(uint32_t(ceil_div(prm.nx, 256)), uint32_t(prm.ny)),
-                                       dim3(256), 0, stream, geom, d_gridB.p, prm.do_wgridding, wplanes[size_t(p)],
+                                       dim3(256), 0, stream, geom, fgeom, d_gridB.p, prm.do_wgridding, wplanes[size_t(p)],
                                        p == 0 ? 1 : 0, d_accT.p);
                     PFB_HIP(hipGetLastError());
                     timer.end();
@@ -804,7 +804,7 @@ struct pfbhip_gridder {
                 if (!fused) {
                     timer.begin(3);
                     hipLaunchKernelGGL(k_pad_screen_T, dim3(uint32_t(ceil_div(info.nu, 256)), uint32_t(prm.ny)),
-                                       dim3(256), 0, stream, geom, d_accT.p, prm.do_wgridding, wplanes[size_t(p)],
+                                       dim3(256), 0, stream, geom, fgeom, d_accT.p, prm.do_wgridding, wplanes[size_t(p)],
                                        d_gridB.p);
                     PFB_HIP(hipGetLastError());
                     timer.end();
@@ -1251,7 +1251,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     g->fused = want_fused && g->rowfft_u.ok && !g->rowfft_u.pl.doubled;
     if (!own_rows && !g->fused) g->rowfft_u.release();
     if (own_rows) (void)g->rowfft_v.init(info.nv);
-    if (g->fused) {
+    {  // the screen geometry serves the fused kernels and the separate pad / crop kernels alike
         FusedGeom &fg = g->fgeom;
         fg.nx = int(prm.nx);
         fg.ny = int(prm.ny);
@@ -1262,10 +1262,10 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         fg.mshift = info.mshift;
         fg.nshift = info.nshift;
         if (prm.do_wgridding) fused_geom_fit(fg);
-        if (prm.verbosity > 0) fprintf(stderr, "[pfbhip] fused w-screen: n-1 polynomial with %d coefficients\n", fg.npoly);
+        if (prm.verbosity > 0) fprintf(stderr, "[pfbhip] w-screen: n-1 polynomial with %d coefficients\n", fg.npoly);
     }
     info.fft_mode = (g->rowfft_v.ok ? 1 : 0) | (g->fused ? 2 : 0) | ((!g->fused && g->rowfft_u.ok) ? 4 : 0);
-    info.screen_poly = g->fused ? g->fgeom.npoly : 0;
+    info.screen_poly = g->fgeom.npoly;
     g->bstride = size_t(prm.ny) * size_t(info.nu);
     g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
     g->d_accT.alloc(size_t(npix));

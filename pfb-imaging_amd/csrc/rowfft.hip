@@ -113,67 +113,6 @@ void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inver
 // fused second-axis passes of the plane transform
 // ---------------------------------------------------------------------------------------
 
-// n - 1 + nshift at image pixel (ix, iy): polynomial in r2 where the field is narrow enough for
-// fused_geom_fit(), the numerically stable closed form otherwise
-__device__ __forceinline__ double fg_t(const FusedGeom &g, int ix, int iy)
-{
-    const double l = g.lshift + double(ix - g.nx / 2) * g.px;
-    const double m = g.mshift + double(iy - g.ny / 2) * g.py;
-    const double r2 = l * l + m * m;
-    if (g.npoly > 0) {
-        const double sv = r2 * g.za + g.zb;
-        double acc = g.pc[0];
-        for (int k = 1; k < g.npoly; ++k) acc = acc * sv + g.pc[k];
-        return acc + g.nshift;
-    }
-    if (r2 <= 1.0) return -r2 / (1.0 + sqrt(1.0 - r2)) + g.nshift;
-    return -sqrt(r2 - 1.0) - 1.0 + g.nshift;
-}
-
-// sin(2 pi r) and cos(2 pi r) for |r| <= 1/2 (the caller has removed the integer part): one fold to
-// |q| <= 1/4, then the Taylor polynomials on |x| <= pi/2 (truncation < 2e-17).  About half the
-// instructions of sincospi(), which repeats the range reduction and handles specials.
-__device__ __forceinline__ void fg_sincos2pi(double r, double &sn, double &cs)
-{
-    const bool fold = fabs(r) > 0.25;
-    const double q = fold ? copysign(0.5, r) - r : r;
-    const double x = q * 6.283185307179586476925286766559;
-    const double x2 = x * x;
-    double ps = 1.0 / 51090942171709440000.0;   // 21!
-    ps = 1.0 / 121645100408832000.0 - ps * x2;  // 19!
-    ps = 1.0 / 355687428096000.0 - ps * x2;     // 17!
-    ps = 1.0 / 1307674368000.0 - ps * x2;       // 15!
-    ps = 1.0 / 6227020800.0 - ps * x2;          // 13!
-    ps = 1.0 / 39916800.0 - ps * x2;            // 11!
-    ps = 1.0 / 362880.0 - ps * x2;              // 9!
-    ps = 1.0 / 5040.0 - ps * x2;                // 7!
-    ps = 1.0 / 120.0 - ps * x2;                 // 5!
-    ps = 1.0 / 6.0 - ps * x2;                   // 3!
-    sn = x - x * x2 * ps;
-    double pc = 1.0 / 1124000727777607680000.0;   // 22!
-    pc = 1.0 / 2432902008176640000.0 - pc * x2;   // 20!
-    pc = 1.0 / 6402373705728000.0 - pc * x2;      // 18!
-    pc = 1.0 / 20922789888000.0 - pc * x2;        // 16!
-    pc = 1.0 / 87178291200.0 - pc * x2;           // 14!
-    pc = 1.0 / 479001600.0 - pc * x2;             // 12!
-    pc = 1.0 / 3628800.0 - pc * x2;               // 10!
-    pc = 1.0 / 40320.0 - pc * x2;                 // 8!
-    pc = 1.0 / 720.0 - pc * x2;                   // 6!
-    pc = 1.0 / 24.0 - pc * x2;                    // 4!
-    pc = 0.5 - pc * x2;                           // 2!
-    const double c0 = 1.0 - x2 * pc;
-    cs = fold ? -c0 : c0;
-}
-
-// image column of uv-column u (-1: u lies in the zero padding)
-__device__ __forceinline__ int fg_ix(const FusedGeom &g, int u)
-{
-    const int hx = g.nx / 2;
-    if (u < g.nx - hx) return u + hx;
-    if (u >= g.nu - hx) return u - (g.nu - hx);
-    return -1;
-}
-
 // Row of B with the unoccupied 32-column blocks read as zero.  The occupancy of the thread's
 // elements is looked up once per workgroup (bit `slot` of mask), not once per element and plane: a
 // byte load in front of every row load doubles the latency of the load phase.
