@@ -1245,10 +1245,14 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     const bool own_rows = !(renv != nullptr && renv[0] == '0');
     const bool want_fused = !(fenv != nullptr && fenv[0] == '0');
     if (own_rows || want_fused) (void)g->rowfft_u.init(info.nu);
-    // Doubled shapes (20480, 24576, 32768 points) run the plain row kernel on both axes but keep the separate pad / crop
-    // kernels: their fused forms carry two transforms' worth of load / epilogue state and spill ~250 VGPRs
-    // (measured on the C5-size grid: 336 ms against ~310 ms unfused for the second axis).
-    g->fused = want_fused && g->rowfft_u.ok && !g->rowfft_u.pl.doubled;
+    // Doubled shapes (20480, 24576, 32768 points) run the plain row kernel on both axes and keep the separate pad / crop
+    // kernels.  Their dedicated fused kernels (k_fused_fft_crop2 / k_fused_pad_fft2: even / odd half transforms combined
+    // pair by pair) hold one half's 16 outputs across the other half's transform and still spill ~100 registers at the
+    // 170-VGPR budget of a 640..1024-thread workgroup: measured 36.8 ms against 35.6 ms unfused for the second axis of
+    // a 16384^2 image / 20480^2 grid with 4 planes, so they stay behind PFBHIP_FUSED_DOUBLED=1 (tests keep them alive).
+    const char *denv = std::getenv("PFBHIP_FUSED_DOUBLED");
+    const bool fuse_doubled = denv != nullptr && denv[0] == '1';
+    g->fused = want_fused && g->rowfft_u.ok && (!g->rowfft_u.pl.doubled || fuse_doubled);
     if (!own_rows && !g->fused) g->rowfft_u.release();
     if (own_rows) (void)g->rowfft_v.init(info.nv);
     {  // the screen geometry serves the fused kernels and the separate pad / crop kernels alike

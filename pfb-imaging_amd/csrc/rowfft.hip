@@ -326,6 +326,149 @@ void fused_geom_fit(FusedGeom &g)
     if (worst <= 4e-16L * fmax) g = trial;
 }
 
+// ---- doubled shapes (N = 2 N1): dedicated fused kernels ---------------------------------------------------
+// The generic kernels above on RfShape2 materialise all 2 x 16 outputs per thread (128 VGPRs) next to the
+// waiting half transform and spill ~250 registers.  Here the even / odd half transforms are combined pair by
+// pair, X[k] = E[k] + w^k O[k], X[k + N1] = E[k] - w^k O[k], and every pair is consumed at once.  The image row
+// does not fit LDS at these sizes: read-modify-write form.
+struct OccLoad2 {
+    const double2 *row;
+    uint32_t mask;
+    int par;
+    __device__ __forceinline__ double2 operator()(int pos, int slot) const
+    {
+        return ((mask >> slot) & 1u) ? row[2 * pos + par] : make_double2(0.0, 0.0);
+    }
+};
+
+template <class S1>
+__global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
+    k_fused_fft_crop2(const double2 *tw, FusedGeom g, const uint8_t *occ, const double2 *B, size_t bstride, FusedPlanes planes,
+                      int do_w, int first, double *accT, FusedFinal fin)
+{
+    extern __shared__ double rf_lds[];
+    const int y = blockIdx.x;
+    double *arow = accT + size_t(y) * g.nx;
+    // samples 2 pos and 2 pos + 1 lie in the same 32-column block: one occupancy mask serves both halves
+    uint32_t mask = 0;
+    rf_for_each_load<S1>(int(threadIdx.x), [&](int pos, int slot) { mask |= (occ[(2 * pos) >> 5] ? 1u : 0u) << slot; });
+    const double2 *__restrict__ tw2 = tw + S1::N;
+    for (int k = 0; k < planes.kp; ++k) {
+        const double2 *row = B + size_t(k) * bstride + size_t(y) * g.nu;
+        OccLoad2 ld_e{row, mask, 0}, ld_o{row, mask, 1};
+        double er[S1::E], ei[S1::E], orr[S1::E], oi[S1::E];
+        int t;
+        rf_row_compute<S1>(tw, ld_e, true, rf_lds, t, er, ei);
+        __builtin_amdgcn_sched_barrier(0);
+        rf_row_compute<S1>(tw, ld_o, true, rf_lds, t, orr, oi);
+        __builtin_amdgcn_sched_barrier(0);
+        rf_opaque(t);
+        const double wk = planes.w[k];
+        const bool last = k == planes.kp - 1;
+        const bool add_img = !(first && k == 0);
+        const bool finalize = last && fin.corr != nullptr;
+#pragma unroll
+        for (int e = 0; e < S1::E; ++e) {
+            const int k1 = S1::out_pos(t, e);
+            const double2 w = tw2[k1];
+            const double tr = orr[e] * w.x - oi[e] * w.y, ti = orr[e] * w.y + oi[e] * w.x;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double vre = h ? er[e] - tr : er[e] + tr, vim = h ? ei[e] - ti : ei[e] + ti;
+                const int ix = fg_ix(g, k1 + h * S1::N);
+                if (ix >= 0) {
+                    double r = vim;  // inverse transform: value = (im, re)
+                    if (do_w) {
+                        double ph = wk * fg_t(g, ix, y);
+                        ph -= rint(ph);
+                        double sn, cs;
+                        fg_sincos2pi(ph, sn, cs);
+                        r = vim * cs + vre * sn;
+                    }
+                    if (add_img) r += arow[ix];
+                    if (finalize) {
+                        const size_t o = size_t(y) * size_t(g.nx) + size_t(ix);
+                        double v = r * fin.corr[o];
+                        if (fin.beam != nullptr) v *= fin.beam[o];
+                        v *= fin.scale;
+                        if (fin.x != nullptr) v += fin.eta * fin.x[o];
+                        fin.out[o] = v;
+                    } else {
+                        arow[ix] = r;
+                    }
+                }
+            }
+            if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the number of sincos chains in flight
+        }
+    }
+}
+
+struct PadLoad2 {
+    PadLoad base;
+    int par;
+    __device__ __forceinline__ double2 operator()(int pos, int slot) const { return base(2 * pos + par, slot); }
+};
+
+template <class S1>
+__global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
+    k_fused_pad_fft2(const double2 *tw, FusedGeom g, const uint8_t *occ, const double *dcT, FusedPrep prep, FusedPlanes planes,
+                     int do_w, double2 *B, size_t bstride)
+{
+    extern __shared__ double rf_lds[];
+    const int y = blockIdx.x;
+    uint32_t omask = 0;  // bit e: column out_pos(e) occupied, bit 16 + e: column N1 + out_pos(e)
+#pragma unroll
+    for (int e = 0; e < S1::E; ++e) {
+        const int k1 = S1::out_pos(int(threadIdx.x), e);
+        omask |= (occ[k1 >> 5] ? 1u : 0u) << e;
+        omask |= (occ[(k1 + S1::N) >> 5] ? 1u : 0u) << (16 + e);
+    }
+    const double2 *__restrict__ tw2 = tw + S1::N;
+    const size_t ro = size_t(y) * size_t(g.nx);
+    for (int k = 0; k < planes.kp; ++k) {
+        PadLoad base{prep.x != nullptr ? prep.x + ro : dcT + ro, prep.x != nullptr ? prep.corr + ro : nullptr,
+                     (prep.x != nullptr && prep.beam != nullptr) ? prep.beam + ro : nullptr, nullptr, g, y, do_w, k, planes.w[k]};
+        PadLoad2 ld_e{base, 0}, ld_o{base, 1};
+        double er[S1::E], ei[S1::E], orr[S1::E], oi[S1::E];
+        int t;
+        rf_row_compute<S1>(tw, ld_e, false, rf_lds, t, er, ei);
+        __builtin_amdgcn_sched_barrier(0);
+        rf_row_compute<S1>(tw, ld_o, false, rf_lds, t, orr, oi);
+        __builtin_amdgcn_sched_barrier(0);
+        rf_opaque(t);
+        double2 *brow = B + size_t(k) * bstride + size_t(y) * g.nu;
+#pragma unroll
+        for (int e = 0; e < S1::E; ++e) {
+            const int k1 = S1::out_pos(t, e);
+            const double2 w = tw2[k1];
+            const double tr = orr[e] * w.x - oi[e] * w.y, ti = orr[e] * w.y + oi[e] * w.x;
+            if ((omask >> e) & 1u) brow[k1] = make_double2(er[e] + tr, ei[e] + ti);
+            if ((omask >> (16 + e)) & 1u) brow[k1 + S1::N] = make_double2(er[e] - tr, ei[e] - ti);
+        }
+    }
+}
+
+template <class S1>
+static void launch_crop2(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev, size_t bstride,
+                         const FusedPlanes &planes, int do_w, bool first, double *accT_dev, const FusedFinal &fin,
+                         hipStream_t stream)
+{
+    static bool attr = false;
+    rf_allow_lds(&k_fused_fft_crop2<S1>, &attr);
+    hipLaunchKernelGGL(k_fused_fft_crop2<S1>, dim3(uint32_t(g.ny)), dim3(S1::T), size_t(S1::LDS_BYTES), stream, pl.twiddle, g,
+                       occ_dev, B_dev, bstride, planes, do_w, first ? 1 : 0, accT_dev, fin);
+}
+template <class S1>
+static void launch_pad2(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev,
+                        const FusedPrep &prep, const FusedPlanes &planes, int do_w, double2 *B_dev, size_t bstride,
+                        hipStream_t stream)
+{
+    static bool attr = false;
+    rf_allow_lds(&k_fused_pad_fft2<S1>, &attr);
+    hipLaunchKernelGGL(k_fused_pad_fft2<S1>, dim3(uint32_t(g.ny)), dim3(S1::T), size_t(S1::LDS_BYTES), stream, pl.twiddle, g,
+                       occ_dev, dcT_dev, prep, planes, do_w, B_dev, bstride);
+}
+
 // The fused kernels transpose one component at a time (N doubles of LDS), which leaves room for the
 // workgroup's image row (nx doubles) when (N + nx) * 8 <= 160 KiB.
 static bool fused_row_fits(int lds_bytes, int nx)
@@ -374,8 +517,7 @@ void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev,
 #undef RF_X
 #define RF_X(L, K)                                                                                                        \
     case 2 * (L << K):                                                                                                    \
-        launch_crop<RfShape2<RfShape<L, K, false>>>(f.pl, g, occ_dev, B_dev, bstride, planes, do_w, first, accT_dev, fin, \
-                                                    stream);                                                              \
+        launch_crop2<RfShape<L, K, false>>(f.pl, g, occ_dev, B_dev, bstride, planes, do_w, first, accT_dev, fin, stream);    \
         break;
         RF_FOR_SHAPES2(RF_X)
 #undef RF_X
@@ -396,7 +538,7 @@ void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, 
 #undef RF_X
 #define RF_X(L, K)                                                                                                      \
     case 2 * (L << K):                                                                                                  \
-        launch_pad<RfShape2<RfShape<L, K, false>>>(f.pl, g, occ_dev, dcT_dev, prep, planes, do_w, B_dev, bstride, stream); \
+        launch_pad2<RfShape<L, K, false>>(f.pl, g, occ_dev, dcT_dev, prep, planes, do_w, B_dev, bstride, stream);          \
         break;
         RF_FOR_SHAPES2(RF_X)
 #undef RF_X

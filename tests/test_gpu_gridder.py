@@ -408,6 +408,39 @@ def test_own_fft_shapes_vs_oracle(nx, ny, center, widen, zscale):
     g.close()
 
 
+@pytest.mark.parametrize("nx,ny", [(900, 14000), (14000, 900)])
+def test_doubled_fft_shapes_vs_oracle(nx, ny, monkeypatch):
+    """A 20480-point axis runs as a DOUBLED row-FFT shape (two 10240-point half transforms + combine): as the
+    first axis (plain kernel) and as the second axis, there both with the separate pad / crop kernels (default)
+    and with the dedicated fused kernels (PFBHIP_FUSED_DOUBLED=1)."""
+    c = make(nrow=1500, npix=64, widen=8.0, zscale=0.02)
+    rng = np.random.default_rng(6)
+    c["nx"], c["ny"] = nx, ny
+    c["cell"] = c["cell"] * 64.0 / max(nx, ny)
+    c["x"] = rng.standard_normal((nx, ny))
+    monkeypatch.delenv("PFBHIP_FUSED_DOUBLED", raising=False)
+    g, kw, mask = gpu_plan(c)
+    assert sorted((g.info["nu"], g.info["nv"])) == [1152, 20480], g.info
+    assert g.info["fft_mode"] & 1 and g.info["fft_mode"] & 6, g.info
+    o = oracle_plan(c, g, kw, mask)
+    d = g.vis2dirty(c["vis"], c["wgt"])
+    v = g.dirty2vis(c["x"])
+    assert rel(d, o.vis2dirty(c["vis"], c["wgt"])) < 2e-9
+    assert rel(v, o.dirty2vis(c["x"])) < 2e-9
+    beam = 1.0 + 0.1 * rng.random((nx, ny))
+    g.set_weights(c["wgt"])
+    h = g.hessian(c["x"], beam=beam, eta=0.3, wsum=7.0)
+    g.close()
+    monkeypatch.setenv("PFBHIP_FUSED_DOUBLED", "1")
+    g1, _, _ = gpu_plan(c)
+    d1 = g1.vis2dirty(c["vis"], c["wgt"])
+    v1 = g1.dirty2vis(c["x"])
+    g1.set_weights(c["wgt"])
+    h1 = g1.hessian(c["x"], beam=beam, eta=0.3, wsum=7.0)
+    g1.close()
+    assert rel(d1, d) < 1e-11 and rel(v1, v) < 1e-11 and rel(h1, h) < 1e-11
+
+
 @pytest.mark.parametrize("eps", [1e-4, 1e-10])
 def test_epsilon_contract_own_fft_path(eps):
     """Accuracy contract at both ends of the range on a grid the hand-written FFT path serves (>= 1024)."""
