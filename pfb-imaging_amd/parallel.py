@@ -145,6 +145,15 @@ class BandComm:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t[0])
 
+    def min_over_ranks(self, value):
+        if self.world_size == 1:
+            return float(value)
+        import torch
+
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN)
+        return float(t[0])
+
     def sum_over_ranks(self, value):
         if self.world_size == 1:
             return float(value)
