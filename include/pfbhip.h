@@ -225,6 +225,29 @@ int pfbhip_psfconv_cg(pfbhip_psfconv *p, int64_t nparts, const int64_t *psf_slot
 int pfbhip_gridder_cg(pfbhip_gridder *g, const double *beam_host, double eta, double wsum, const double *rhs_host,
                       double *x_host, int has_x0, double tol, int maxit, int minit, pfbhip_cg_info *info);
 
+/* ---- power method on the device (spectral norm of a Hessian) ------------
+ * Replaces power_method / power_method_numba (src/pfb_imaging/opt/power_method.py:40-148) as called on
+ * precond.dot / hess.dot for `hess_norm` (core/sara.py:200-209, deconv/pfb.py:118-126) -- and the per-actor
+ * form power_method_dist (:178-208) when a communicator is passed.  b_host: start vector in (any non-zero norm; the
+ * reference draws randn), normalised last iterate out.  Stops when |beta - beta_prev| / beta_prev <= tol or after
+ * maxit iterations (status 1). */
+typedef struct pfbhip_pm_info {
+    int32_t iters;
+    int32_t status; /* 0 converged, 1 maxit reached */
+    double eps;
+    double beta; /* Rayleigh quotient (bp . A bp) / (bp . bp) of the last iteration */
+} pfbhip_pm_info;
+typedef struct pfbhip_comm pfbhip_comm; /* RCCL communicator, see below */
+/* A = blockdiag_b( scale[b] sum_p beam_p (PSF_p * (beam_p .)) + eta[b] I ) on a cube (nband, nx, ny); band b owns
+ * nparts[b] consecutive entries of psf_slots / beam_slots of its plan pcs[b] (as in pfbhip_primal_dual).
+ * comm != NULL: the arrays hold this rank's LOCAL bands, the three dots are all-reduced. */
+int pfbhip_psfconv_power_method(pfbhip_psfconv *const *pcs, int64_t nband, const int64_t *nparts, const int64_t *psf_slots,
+                                const int64_t *beam_slots, const double *scale, const double *eta, double *b_host, double tol,
+                                int maxit, pfbhip_comm *comm, pfbhip_pm_info *info);
+/* A = beam * R^H W R (beam * .) / wsum + eta * I (exact Hessian, weights bound by set_weights), image (nx, ny) */
+int pfbhip_gridder_power_method(pfbhip_gridder *g, const double *beam_host, double eta, double wsum, double *b_host,
+                                double tol, int maxit, pfbhip_pm_info *info);
+
 /* ---- uv-cell counts / Briggs weights (utils/weighting.py:81-208) ------ */
 /* cell index (u_idx*ny+v_idx, -1 if masked / out of bounds): the bit-exact index map. */
 int pfbhip_uvcell_index(const double *uvw_host, const double *freq_host, const uint8_t *mask_host, int64_t nrow,
@@ -290,7 +313,6 @@ int pfbhip_positivity_dev(double *x_dev, int64_t nband, int64_t n, int mode);
  * comm == NULL: all nband bands are on this device.  comm != NULL (one process per GPU, every rank calls
  * collectively): the arrays hold this rank's nband LOCAL bands; the band sum of the dual update, the
  * "any band <= 0" test of positivity mode 2 and the convergence norms are completed with all-reduces. */
-typedef struct pfbhip_comm pfbhip_comm; /* RCCL communicator, see below */
 typedef struct pfbhip_pd_info {
     int32_t iters;
     int32_t status; /* 0 converged, 1 maxit reached */

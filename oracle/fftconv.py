@@ -120,3 +120,21 @@ def pcg(aop, b, x0=None, tol=1e-5, maxit=500, minit=100):
         if abs(epsp - eps) < 1e-3 * tol:
             stall += 1
     return x
+
+
+def power_method(aop, imsize, b0, tol=1e-5, maxit=250):
+    """power_method_numba / power_method (/root/reference/src/pfb_imaging/opt/power_method.py:40-148) with an
+    explicit start vector; returns (beta, b, iterations)."""
+    b = b0 / np.linalg.norm(b0)
+    beta, eps, k = 1.0, 1.0, 0
+    bp = b.copy()
+    while eps > tol and k < maxit:
+        b = aop(bp)
+        bnorm = np.linalg.norm(b)
+        betap = beta
+        beta = np.vdot(bp, b) / np.vdot(bp, bp)
+        b = b / bnorm
+        eps = np.abs(beta - betap) / betap
+        k += 1
+        bp[...] = b
+    return float(beta), b, k

@@ -49,6 +49,10 @@ class PDInfo(ct.Structure):
     _fields_ = [("iters", i32), ("status", i32), ("eps", f64)]
 
 
+class PMInfo(ct.Structure):
+    _fields_ = [("iters", i32), ("status", i32), ("eps", f64), ("beta", f64)]
+
+
 class CGInfo(ct.Structure):
     _fields_ = [("iters", i32), ("status", i32), ("eps", f64), ("phi", f64)]
 
@@ -69,6 +73,7 @@ SYMBOLS = (
     "pfbhip_psi_create", "pfbhip_psi_destroy", "pfbhip_psi_shape", "pfbhip_psi_dot", "pfbhip_psi_hdot",
     "pfbhip_psi_dot_dev", "pfbhip_psi_hdot_dev", "pfbhip_dual_update", "pfbhip_l21_vtilde_sum_dev",
     "pfbhip_l21_scale_dev", "pfbhip_prox_21m", "pfbhip_positivity", "pfbhip_positivity_dev", "pfbhip_primal_dual",
+    "pfbhip_psfconv_power_method", "pfbhip_gridder_power_method",
     "pfbhip_psfconv_create", "pfbhip_psfconv_destroy", "pfbhip_psfconv_set_psfhat", "pfbhip_psfconv_set_beam",
     "pfbhip_psfconv_apply", "pfbhip_psfconv_apply_dev", "pfbhip_psfconv_cg",
     "pfbhip_uvcell_index", "pfbhip_compute_counts", "pfbhip_counts_divide", "pfbhip_box_sum_counts",

@@ -160,4 +160,78 @@ struct DevCG {
     }
 };
 
+// ---- power method ---------------------------------------------------------------------------------------
+// Mirrors power_method_numba (/root/reference/src/pfb_imaging/opt/power_method.py:40-93): b <- b0 / ||b0||; per
+// iteration b = A bp, beta = (bp.b) / (bp.bp), b /= ||b||, eps = |beta - beta_prev| / beta_prev, bp <- b; stops
+// when eps <= tol or after maxit iterations.  One reduction pass (three dots) and one scaling pass per iteration
+// instead of the reference's norm + vdot pair + normalise + copy; one host round trip (three scalars).
+
+// partials [0] = b.b, [1] = bp.b, [2] = bp.bp
+static __global__ void __launch_bounds__(CG_THREADS) k_pm_dots(int64_t n, const double *bp, const double *b, double *partials)
+{
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = blockIdx.x * int64_t(CG_THREADS) + threadIdx.x; i < n; i += int64_t(CG_BLOCKS) * CG_THREADS) {
+        const double bi = b[i], pi = bp[i];
+        v[0] += bi * bi;
+        v[1] += pi * bi;
+        v[2] += pi * pi;
+    }
+    block_reduce_store<3>(v, partials);
+}
+static __global__ void __launch_bounds__(CG_THREADS) k_pm_scale(int64_t n, double s, const double *b, double *bp)
+{
+    for (int64_t i = blockIdx.x * int64_t(CG_THREADS) + threadIdx.x; i < n; i += int64_t(CG_BLOCKS) * CG_THREADS) bp[i] = b[i] * s;
+}
+
+struct DevPower {
+    int64_t n;
+    hipStream_t stream;
+    DevBuf<double> b, partials;
+    std::vector<double> host;
+    DevPower(int64_t n_, hipStream_t st) : n(n_), stream(st), b(size_t(n_)), partials(size_t(3) * CG_BLOCKS), host(size_t(3) * CG_BLOCKS) {}
+    // sums over this device; `allreduce(s)` (3 doubles, in place) completes them when the vector spans ranks
+    template <class Reduce>
+    void dots(const double *bp, const double *bv, double *s, Reduce &&allreduce)
+    {
+        hipLaunchKernelGGL(k_pm_dots, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, stream, n, bp, bv, partials.p);
+        PFB_HIP(hipGetLastError());
+        PFB_HIP(hipMemcpyAsync(host.data(), partials.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+        PFB_HIP(hipStreamSynchronize(stream));
+        for (int k = 0; k < 3; ++k) {
+            double t = 0.0;
+            for (int i = 0; i < CG_BLOCKS; ++i) t += host[size_t(k) * CG_BLOCKS + i];
+            s[k] = t;
+        }
+        allreduce(s);
+    }
+    // bp_dev: b0 on entry (any non-zero norm), the normalised last iterate on exit.  aop(in, out) enqueues on `stream`.
+    template <class Op, class Reduce>
+    void run(Op &&aop, Reduce &&allreduce, double *bp_dev, double tol, int maxit, pfbhip_pm_info *info)
+    {
+        double s[3];
+        dots(bp_dev, bp_dev, s, allreduce);
+        PFB_REQUIRE(s[0] > 0.0 && std::isfinite(s[0]), "the power method needs a non-zero, finite start vector");
+        hipLaunchKernelGGL(k_pm_scale, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, stream, n, 1.0 / std::sqrt(s[0]), bp_dev, bp_dev);
+        double beta = 1.0, eps = 1.0;
+        int k = 0;
+        while (eps > tol && k < maxit) {
+            aop(bp_dev, b.p);
+            dots(bp_dev, b.p, s, allreduce);
+            const double betap = beta;
+            beta = s[1] / s[2];
+            hipLaunchKernelGGL(k_pm_scale, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, stream, n, 1.0 / std::sqrt(s[0]), b.p, bp_dev);
+            PFB_HIP(hipGetLastError());
+            eps = std::fabs(beta - betap) / betap;
+            ++k;
+        }
+        PFB_HIP(hipStreamSynchronize(stream));
+        if (info) {
+            info->iters = k;
+            info->status = (k == maxit && eps > tol) ? 1 : 0;
+            info->eps = eps;
+            info->beta = beta;
+        }
+    }
+};
+
 }  // namespace pfbhip

@@ -1594,6 +1594,30 @@ int pfbhip_gridder_cg(pfbhip_gridder *g, const double *beam_host, double eta, do
     });
 }
 
+int pfbhip_gridder_power_method(pfbhip_gridder *g, const double *beam_host, double eta, double wsum, double *b_host, double tol,
+                                int maxit, pfbhip_pm_info *info)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && b_host && maxit >= 0, "bad arguments");
+        PFB_REQUIRE(g->weights_bound, "call pfbhip_gridder_set_weights before the power method");
+        hipStream_t st = g->stream;
+        const int64_t npix = g->prm.nx * g->prm.ny;
+        DevBuf<double> bp{size_t(npix)};
+        PFB_HIP(hipMemcpyAsync(bp.p, b_host, size_t(npix) * sizeof(double), hipMemcpyHostToDevice, st));
+        const double *beam = nullptr;
+        if (beam_host) {
+            g->d_beam.ensure(size_t(npix));
+            PFB_HIP(hipMemcpyAsync(g->d_beam.p, beam_host, size_t(npix) * sizeof(double), hipMemcpyHostToDevice, st));
+            beam = g->d_beam.p;
+        }
+        DevPower pm(npix, st);
+        pm.run([&](const double *in, double *out) { hessian_dev_impl(g, in, beam, eta, wsum, out); }, [](double *) {}, bp.p, tol,
+               maxit, info);
+        PFB_HIP(hipMemcpyAsync(b_host, bp.p, size_t(npix) * sizeof(double), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
 int pfbhip_gridder_degrid_dev(pfbhip_gridder *g, const double *dirty_dev, double *vis_sorted_dev)
 {
     return guarded([&] {

@@ -200,4 +200,65 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
     });
 }
 
+int pfbhip_psfconv_power_method(pfbhip_psfconv *const *pcs, int64_t nband, const int64_t *nparts, const int64_t *psf_slots,
+                                const int64_t *beam_slots, const double *scale, const double *eta, double *b_host, double tol,
+                                int maxit, pfbhip_comm *comm, pfbhip_pm_info *info)
+{
+    return guarded([&] {
+        PFB_REQUIRE(pcs && nparts && psf_slots && beam_slots && scale && eta && b_host && nband >= 1 && maxit >= 0, "bad arguments");
+        int64_t nx = 0, ny = 0, px, py;
+        for (int64_t b = 0; b < nband; ++b) {
+            PFB_REQUIRE(pcs[b] != nullptr, "band %lld has no PSF plan", (long long)b);
+            psfconv_geometry(pcs[b], &px, &py);
+            if (b == 0) nx = px, ny = py;
+            PFB_REQUIRE(px == nx && py == ny, "band %lld is (%lld, %lld), band 0 is (%lld, %lld)", (long long)b, (long long)px,
+                        (long long)py, (long long)nx, (long long)ny);
+        }
+        const size_t npix = size_t(nx) * size_t(ny), nimg = size_t(nband) * npix;
+        hipStream_t st = psfconv_stream(pcs[0]);
+        struct Restore {
+            std::vector<std::pair<pfbhip_psfconv *, hipStream_t>> plans;
+            ~Restore()
+            {
+                for (auto it = plans.rbegin(); it != plans.rend(); ++it) {
+                    try {
+                        (void)psfconv_swap_stream(it->first, it->second);
+                    } catch (...) {
+                    }
+                }
+            }
+        } restore;
+        for (int64_t b = 1; b < nband; ++b) {
+            bool seen = pcs[b] == pcs[0];
+            for (auto &pr : restore.plans) seen = seen || pr.first == pcs[b];
+            if (!seen) restore.plans.emplace_back(pcs[b], psfconv_swap_stream(pcs[b], st));
+        }
+        std::vector<int64_t> off(size_t(nband) + 1, 0);
+        for (int64_t b = 0; b < nband; ++b) {
+            PFB_REQUIRE(nparts[b] >= 1, "band %lld has no partitions", (long long)b);
+            off[size_t(b) + 1] = off[size_t(b)] + nparts[b];
+        }
+        DevBuf<double> bp(nimg), red(comm != nullptr ? 3 : 0);
+        PFB_HIP(hipMemcpyAsync(bp.p, b_host, nimg * sizeof(double), hipMemcpyHostToDevice, st));
+        DevPower pm(int64_t(nimg), st);
+        auto aop = [&](const double *in, double *out) {
+            for (int64_t b = 0; b < nband; ++b)
+                for (int64_t q = off[size_t(b)]; q < off[size_t(b) + 1]; ++q)
+                    psfconv_apply_async(pcs[b], in + size_t(b) * npix, psf_slots[q], beam_slots[q], 0, 0.0, scale[b],
+                                        q == off[size_t(b)] ? eta[b] : 0.0, q > off[size_t(b)], out + size_t(b) * npix);
+        };
+        auto allreduce = [&](double *s) {
+            if (comm == nullptr) return;
+            PFB_HIP(hipMemcpyAsync(red.p, s, 3 * sizeof(double), hipMemcpyHostToDevice, st));
+            PFB_HIP(hipStreamSynchronize(st));
+            PFB_CHECK_STATUS(pfbhip_comm_allreduce_sum(comm, red.p, red.p, 3));
+            PFB_HIP(hipMemcpy(s, red.p, 3 * sizeof(double), hipMemcpyDeviceToHost));
+        };
+        pm.run(aop, allreduce, bp.p, tol, maxit, info);
+        PFB_HIP(hipMemcpyAsync(b_host, bp.p, nimg * sizeof(double), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+
 }  // extern "C"

@@ -7,6 +7,10 @@ prox/l21.py:15-50 (``L21``).  When the gradient is the closure of the forward-ba
 ``solve`` runs the whole loop on the device (``pfbhip_primal_dual``: one scalar round trip per iteration).
 Any other gradient callable runs the reference's loop with the GPU dictionary / dual update and the
 reference's own host-side vector steps.
+
+``power_method`` (opt/power_method.py:40-148) is here too: the spectral norm of ``hess.dot`` that sets the
+primal-dual step sizes (core/sara.py:200-209, deconv/pfb.py:118-126), iterated on the device when ``aop`` is the
+``dot`` of a device-resident Hessian.
 """
 
 import ctypes as ct
@@ -14,7 +18,7 @@ import ctypes as ct
 import numpy as np
 
 from . import _lib
-from ._lib import PDInfo, check, cint, f64, i64, lib, ptr
+from ._lib import PDInfo, PMInfo, check, cint, f64, i64, lib, ptr
 from .operators.psi import Psi, PsiNocopyt
 from .prox import dual_update_numba_fast, prox_21m_numba
 
@@ -238,3 +242,84 @@ class PrimalDual:
             np.copyto(vp, v)
         self.last = dict(iters=k, status=0 if eps < self.tol else 1, eps=eps)
         return x
+
+
+def _pm_device(aop, imsize, b):
+    """(call, comm) running the whole power iteration on the device for ``aop``, or None: ``aop`` must be the bound
+    ``dot`` of a HessPSF / HessTreeRay (cube) or the bound ``hessian`` of a Gridder with no extra arguments."""
+    from .operators.hessian import HessPSF, HessTreeRay
+    from .wgridder import Gridder
+
+    owner = getattr(aop, "__self__", None)
+    fn = getattr(aop, "__func__", None)
+    if isinstance(owner, Gridder) and fn is Gridder.hessian and tuple(imsize) == (owner.nx, owner.ny):
+        def call(b, tol, maxit, info):
+            check(lib().pfbhip_gridder_power_method(owner._h, None, f64(0.0), f64(0.0), ptr(b), f64(tol), cint(maxit),
+                                                    ct.byref(info)))
+            return b
+        return call
+    if isinstance(owner, (HessPSF, HessTreeRay)) and fn is type(owner).dot and len(imsize) == 3:
+        hb = PrimalDual._hess_bands(owner, imsize[0])
+        if hb is None:
+            return None
+        bands, comm, local = hb
+
+        def call(b, tol, maxit, info):
+            nloc = len(local)
+            bs = np.ascontiguousarray(b[local])
+            handles = (ct.c_void_p * nloc)(*[x[0]._h for x in bands])
+            nparts = np.array([len(x[1]) for x in bands], dtype=np.int64)
+            psf_slots = np.array([s for x in bands for s in x[1]], dtype=np.int64)
+            beam_slots = np.array([s for x in bands for s in x[2]], dtype=np.int64)
+            scale = np.array([x[3] for x in bands], dtype=np.float64)
+            eta = np.array([x[4] for x in bands], dtype=np.float64)
+            check(lib().pfbhip_psfconv_power_method(handles, i64(nloc), ptr(nparts), ptr(psf_slots), ptr(beam_slots),
+                                                    ptr(scale), ptr(eta), ptr(bs), f64(tol), cint(maxit),
+                                                    None if comm is None else comm._h, ct.byref(info)))
+            if comm is None:
+                return bs
+            out = np.zeros(b.shape)
+            out[local] = bs
+            return comm.allreduce_sum(out).reshape(b.shape)
+        return call
+    return None
+
+
+def power_method(aop, imsize, b0=None, tol=1e-5, maxit=250, verbosity=1, report_freq=25):
+    """Largest eigenvalue of the symmetric operator ``aop`` by power iteration; returns ``(beta, b)`` like
+    opt/power_method.py:40-93 (``power_method_numba``) and :96-148 (``power_method``): ``b`` starts at ``b0 / ||b0||``
+    (``randn`` when None), ``beta = (bp . A bp) / (bp . bp)``, stop when ``|beta - beta_prev| / beta_prev <= tol``.
+
+    The iteration stays on the device (one scalar round trip per iteration) when ``aop`` is ``HessPSF.dot`` /
+    ``HessTreeRay.dot`` / ``Gridder.hessian`` of this package; any other callable runs the reference's host loop
+    around it.
+    """
+    if b0 is None:
+        b = np.random.randn(*imsize)
+    else:
+        b = np.array(b0, dtype=np.float64)
+    if b.shape != tuple(imsize):
+        raise ValueError(f"b0 shape {b.shape} != {tuple(imsize)}")
+    dev = _pm_device(aop, imsize, b)
+    if dev is not None:
+        info = PMInfo()
+        b = dev(np.ascontiguousarray(b), tol, maxit, info)
+        power_method.last = dict(iters=int(info.iters), status=int(info.status), eps=float(info.eps))
+        return float(info.beta), b
+    b /= np.linalg.norm(b)
+    beta, eps, k = 1.0, 1.0, 0
+    bp = b.copy()
+    while eps > tol and k < maxit:
+        b = aop(bp)
+        bnorm = np.linalg.norm(b)
+        betap = beta
+        beta = float(np.vdot(bp, b) / np.vdot(bp, bp))
+        b = b / bnorm  # aop may return an internal buffer (HessPSF.dot does): never scale it in place
+        eps = abs(beta - betap) / betap
+        k += 1
+        bp[...] = b
+    power_method.last = dict(iters=k, status=int(k == maxit and eps > tol), eps=eps)
+    return beta, b
+
+
+power_method_numba = power_method

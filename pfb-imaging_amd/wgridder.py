@@ -18,7 +18,7 @@ import zlib
 import numpy as np
 
 from . import _lib
-from ._lib import CGInfo, GridderInfo, GridderParams, as_c, check, cint, f64, i64, lib, ptr
+from ._lib import CGInfo, PMInfo, GridderInfo, GridderParams, as_c, check, cint, f64, i64, lib, ptr
 
 
 class Gridder:
@@ -136,6 +136,16 @@ class Gridder:
                                       ct.byref(info)))
         self.last_cg = dict(iters=info.iters, status=info.status, eps=info.eps, phi=info.phi)
         return x
+
+    def power_method(self, b0, beam=None, eta=0.0, wsum=0.0, tol=1e-5, maxit=250):
+        """On-device power iteration on :meth:`hessian` (power_method_numba semantics): returns ``(beta, b)``."""
+        b = self._img(b0, "b0").copy()
+        beam = None if beam is None else self._img(beam, "beam")
+        info = PMInfo()
+        check(lib().pfbhip_gridder_power_method(self._h, ptr(beam), f64(eta or 0.0), f64(wsum or 0.0), ptr(b), f64(tol),
+                                                cint(maxit), ct.byref(info)))
+        self.last_pm = dict(iters=info.iters, status=info.status, eps=info.eps)
+        return float(info.beta), b
 
     # -- introspection (parity tests, bench) --------------------------------
     def binmap(self):

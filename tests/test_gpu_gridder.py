@@ -290,6 +290,30 @@ def test_gridder_cg_matches_oracle_pcg():
     g.close()
 
 
+def test_gridder_power_method_matches_oracle():
+    """Spectral norm of the exact Hessian: the device-resident iteration against the numpy restatement
+    (opt/power_method.py:40-93) around the oracle gridder, and through opt.power_method(g.hessian, ...)."""
+    from oracle.fftconv import power_method as pm_oracle
+    from pfb_imaging_amd.opt import power_method
+
+    c = make(nrow=2500, npix=32, widen=20.0)
+    g, gkw, mask = gpu_plan(c)
+    g.set_weights(c["wgt"])
+    wsum = c["wgt"][mask != 0].sum()
+    b0 = np.random.default_rng(8).standard_normal((c["nx"], c["ny"]))
+    o = oracle_plan(c, g, gkw, mask)
+    rbeta, rb, rk = pm_oracle(lambda z: o.vis2dirty(o.dirty2vis(z), c["wgt"]) / wsum + 0.1 * z, b0.shape, b0.copy(), tol=0.0,
+                              maxit=15)
+    beta, b = g.power_method(b0, eta=0.1, wsum=wsum, tol=0.0, maxit=15)
+    assert g.last_pm["iters"] == 15 == rk
+    assert abs(beta - rbeta) < 1e-8 * rbeta and rel(b, rb) < 1e-6
+    # the reference's call form; eta = 0, wsum = 1 are Gridder.hessian's defaults
+    beta2, b2 = power_method(g.hessian, b0.shape, b0=b0, tol=0.0, maxit=15, verbosity=0)
+    rbeta2, rb2, _ = pm_oracle(lambda z: o.vis2dirty(o.dirty2vis(z), c["wgt"]), b0.shape, b0.copy(), tol=0.0, maxit=15)
+    assert abs(beta2 - rbeta2) < 1e-8 * rbeta2 and rel(b2, rb2) < 1e-6
+    g.close()
+
+
 def test_residual_from_partitions_properties():
     """/root/reference/tests/test_imager_pass2.py:117-153."""
     from pfb_imaging_amd.operators.gridder import residual_from_partitions

@@ -319,3 +319,67 @@ def test_psfconv_rowfft_pipeline(is_complex, nx, nxp, nyp, monkeypatch):
         pc.close()
     for i in range(len(cases)):
         assert rel(results[(None, i)], results[("0", i)]) < 1e-12
+
+
+def test_power_method_on_device():
+    """power_method (opt/power_method.py:40-148) as called for hess_norm (core/sara.py:200-209): the device-resident
+    iteration on HessPSF.dot / HessTreeRay.dot against the numpy restatement around the oracle's Hessian, the host
+    loop around an arbitrary callable, and the dense eigenvalue on a tiny image."""
+    from pfb_imaging_amd.opt import power_method, power_method_numba
+    from pfb_imaging_amd.operators.hessian import HessPSF, HessTreeRay
+
+    psf, psfhat, abspsf, x, beam = _psf_case(nband=2, nx=32, ny=32, nxp=64, nyp=64, seed=5)
+    eta = np.array([0.1, 0.2])
+    h = HessPSF(32, 32, abspsf, beam=beam, eta=eta)
+    rng = np.random.default_rng(11)
+    b0 = rng.standard_normal(x.shape)
+    b0c = b0.copy()
+
+    def oracle_op(z):
+        return fftconv.hess_psf_dot(z, abspsf, 64, beam=beam, eta=eta)
+
+    # a fixed number of iterations (tol = 0) compares the iterates themselves
+    beta, b = power_method(h.dot, x.shape, b0=b0, tol=0.0, maxit=25, verbosity=0)
+    rbeta, rb, rk = fftconv.power_method(oracle_op, x.shape, b0c.copy(), tol=0.0, maxit=25)
+    assert power_method.last["iters"] == 25 == rk and power_method.last["status"] == 1
+    assert abs(beta - rbeta) < 1e-11 * abs(rbeta) and rel(b, rb) < 1e-9
+    assert np.array_equal(b0, b0c)  # the start vector is not mutated
+    assert abs(np.linalg.norm(b) - 1.0) < 1e-12
+    # converged run: same iteration count and eigenvalue; the alias the reference imports
+    beta2, _ = power_method_numba(h.dot, x.shape, b0=b0, tol=1e-7, maxit=500, verbosity=0)
+    rbeta2, _, rk2 = fftconv.power_method(oracle_op, x.shape, b0c.copy(), tol=1e-7, maxit=500)
+    assert power_method.last["status"] == 0 and abs(power_method.last["iters"] - rk2) <= 1
+    assert abs(beta2 - rbeta2) < 1e-6 * rbeta2
+    # an arbitrary callable takes the host loop (and may return its internal buffer, like HessPSF.dot)
+    beta3, b3 = power_method(lambda z: h.dot(z), x.shape, b0=b0, tol=0.0, maxit=25, verbosity=0)
+    assert abs(beta3 - rbeta) < 1e-11 * abs(rbeta) and rel(b3, rb) < 1e-9
+    # b0 = None draws the start vector
+    beta4, _ = power_method(h.dot, x.shape, tol=1e-6, maxit=500, verbosity=0)
+    assert abs(beta4 - rbeta2) < 1e-3 * rbeta2
+    with pytest.raises(ValueError):
+        power_method(h.dot, x.shape, b0=b0[0])
+    with pytest.raises(ValueError):
+        power_method(h.dot, x.shape, b0=np.zeros(x.shape))
+
+    # dense check: 8 x 8 image, the matrix from unit vectors
+    psf, psfhat, abspsf, x, beam = _psf_case(nband=1, nx=8, ny=8, nxp=16, nyp=16, seed=6)
+    h8 = HessPSF(8, 8, abspsf, beam=beam, eta=0.05, taper_width=2)
+    mat = np.stack([h8.dot(e.reshape(1, 8, 8)).copy().ravel() for e in np.eye(64)], axis=1)
+    lam = np.linalg.eigvalsh(0.5 * (mat + mat.T))[-1]
+    beta8, _ = power_method(h8.dot, (1, 8, 8), b0=rng.standard_normal((1, 8, 8)), tol=1e-13, maxit=5000, verbosity=0)
+    assert abs(beta8 - lam) < 1e-8 * lam
+
+    # HessTreeRay (one plan per band, wsum scaling)
+    nband, nx, ny, nxp, nyp = 3, 16, 16, 32, 32
+    ppb = [_tree_parts(nx, ny, nxp, nyp, 2, 1, 20 + k) for k in range(nband)]
+    etas = np.array([0.1, 0.2, 0.3])
+    wsum_tot = sum(sum(q["wsum"][0] for q in p) for p in ppb)
+    hr = HessTreeRay(ppb, nx, ny, nxp, nyp, etas=etas, wsums=wsum_tot)
+    b0 = rng.standard_normal((nband, nx, ny))
+
+    def tree_op(z):
+        return np.stack([fftconv.hessian_tree_dot(z[k], ppb[k], nxp, nyp, eta=etas[k], wsum=wsum_tot)[0] for k in range(nband)])
+
+    betat, bt = power_method(hr.dot, b0.shape, b0=b0, tol=0.0, maxit=20, verbosity=0)
+    rbt, rbv, _ = fftconv.power_method(tree_op, b0.shape, b0.copy(), tol=0.0, maxit=20)
+    assert abs(betat - rbt) < 1e-11 * abs(rbt) and rel(bt, rbv) < 1e-9
