@@ -15,6 +15,11 @@
 
 #include "common.hpp"
 
+// the kernels below are internal to each translation unit that includes this header; not every unit uses all of them
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wunneeded-internal-declaration"
+#pragma clang diagnostic ignored "-Wunused-function"
+
 namespace pfbhip {
 
 constexpr int CG_BLOCKS = 1024;
@@ -235,3 +240,5 @@ struct DevPower {
 };
 
 }  // namespace pfbhip
+
+#pragma clang diagnostic pop

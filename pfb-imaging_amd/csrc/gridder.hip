@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <string>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -113,18 +114,23 @@ __global__ void k_keys(MapArgs m, uint32_t *keys, uint32_t *idx)
     VisPos p = vis_position(m, i);
     uint32_t key = tile_of(m, p.iu0, p.iv0);
     if (m.key_planes > 1) key = key * uint32_t(m.key_planes) + uint32_t(min(max(p.p0, 0), m.key_planes - 1));
+    if (m.key_sub > 1) {
+        const uint32_t lu = uint32_t(wrap_index(p.iu0, m.nu)) % TILE, lv = uint32_t(wrap_index(p.iv0, m.nv)) % TILE;
+        key = key * 64u + (lu >> 2) * 8u + (lv >> 2);
+    }
     keys[i] = key;
 }
 
-// tstart[t] = first sorted position whose key >= t  (t = 0..ntiles); tstart[ntiles] = nactive
-__global__ void k_tile_start(const uint32_t *keys, int64_t n, uint32_t ntiles, uint32_t *tstart)
+// tstart[t] = first sorted position whose key >= t * sub  (t = 0..ntiles); tstart[ntiles] = nactive
+__global__ void k_tile_start(const uint32_t *keys, int64_t n, uint32_t ntiles, uint32_t sub, uint32_t *tstart)
 {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > ntiles) return;
+    const uint64_t bound = uint64_t(t) * sub;
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < t) lo = mid + 1;
+        if (uint64_t(keys[mid]) < bound) lo = mid + 1;
         else hi = mid;
     }
     tstart[t] = uint32_t(lo);
@@ -617,10 +623,39 @@ struct pfbhip_gridder {
                            d_grid.p);
     }
     template <int W>
+    size_t lds_bytes_blk(int kp_alloc) const
+    {
+        constexpr int D = kernel_poly_degree_c(W);
+        return (size_t(2) * size_t(kp_alloc) * tile_rows(W) * tile_stride(W) + size_t(W) * (D + 1) +
+                size_t(blk_threads(kp_alloc) / 64) * 2 * BLK_SCRATCH) * sizeof(double);
+    }
+    template <int W, int KP>
+    void launch_grid_blk_wk(const GroupArgs &ga, const double2 *sval)
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_blk<W, KP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_blk<W>(KP_MAX))));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_grid_blk<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds_bytes_blk<W>(kp_max), stream, ga, sval,
+                           d_grid.p);
+    }
+    bool scatter_blk = true;  // register-footprint scatter (k_grid_blk); PFBHIP_SCATTER=walk selects k_grid_mp
+    template <int W>
     void launch_grid_mp_w(int plane0, int kp, const double2 *sval)
     {
         GroupArgs ga = group_args(plane0, kp);
         if (ga.a.nwork == 0) return;
+        if (scatter_blk) {
+            switch (kp) {
+                case 1: launch_grid_blk_wk<W, 1>(ga, sval); break;
+                case 2: launch_grid_blk_wk<W, 2>(ga, sval); break;
+                case 3: launch_grid_blk_wk<W, 3>(ga, sval); break;
+                default: launch_grid_blk_wk<W, 4>(ga, sval); break;
+            }
+            return;
+        }
         switch (kp) {
             case 1: launch_grid_mp_wk<W, 1>(ga, sval); break;
             case 2: launch_grid_mp_wk<W, 2>(ga, sval); break;
@@ -1128,6 +1163,10 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
                               info.ntiles * info.nplanes < (int64_t(1) << 32) - 2;
     m.key_planes = plane_sorted ? int(info.nplanes) : 1;
     const int64_t nkeys = info.ntiles * m.key_planes;
+    // register-footprint scatter (k_grid_blk): runs of visibilities whose footprint origins share a 4 x 4-cell block
+    const char *senv = std::getenv("PFBHIP_SCATTER");
+    g->scatter_blk = !(senv != nullptr && std::string(senv) == "walk");
+    m.key_sub = (g->scatter_blk && nkeys * 64 < (int64_t(1) << 32) - 2) ? 64 : 1;
     std::vector<WorkItem> work;
     g->work_off.clear();
     g->work_cnt.clear();
@@ -1143,7 +1182,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         PFB_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k_in.p, k_out.p, v_in.p, v_out.p, int(g->nvis), 0,
                                                    32, st));
         DevBuf<uint32_t> d_tstart(size_t(nkeys) + 1);
-        hipLaunchKernelGGL(k_tile_start, blocks1d(nkeys + 1), dim3(256), 0, st, k_out.p, g->nvis, uint32_t(nkeys),
+        hipLaunchKernelGGL(k_tile_start, blocks1d(nkeys + 1), dim3(256), 0, st, k_out.p, g->nvis, uint32_t(nkeys), uint32_t(m.key_sub),
                            d_tstart.p);
         PFB_HIP(hipGetLastError());
         lap("keys + radix sort");

@@ -176,6 +176,206 @@ __global__ void __launch_bounds__(MP_THREADS) k_grid_mp(GroupArgs ga, const doub
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Scatter, register-footprint form (k_grid_blk).
+//
+// k_grid_mp above pays 2 W^2 LDS f64 atomics per visibility and plane, and the LDS atomic pipe (~12 cycles per
+// wave instruction) is its floor.  Visibilities are sorted by (tile, 4 x 4-cell block of the footprint origin), so
+// consecutive visibilities mostly share a block: their footprints all lie inside the (W + 3)^2 cells anchored at
+// the block origin.  Here a wavefront takes ONE visibility at a time and keeps that (W + 3)^2 footprint of every
+// plane in REGISTERS (lane = (row group g, column c), NR rows per lane); a visibility costs 1 + 2 KP FMAs per held
+// cell and no atomic; the footprint goes to the LDS tile (ds_add_f64) only when the block changes.  The u / v kernel
+// values are evaluated by lanes 0..15 / 16..31 (per-lane coefficient registers, as above) and handed to the cells
+// through a per-wave LDS scratch line with zero guards, read at offset (cell - origin offset).
+// Any visibility order is correct; the sort only sets the run length (C2: 14.6 visibilities per block).
+// 12 waves (3 per SIMD) while the accumulators fit 168 VGPRs (KP <= 3), 8 waves otherwise: a third wave per SIMD overlaps one
+// wave's flush (LDS pipe) with the others' FMAs
+__host__ __device__ constexpr int blk_threads(int KP) { return KP <= 3 ? 768 : 512; }
+constexpr int BLK_CELLS = 4;                       // block edge in grid cells
+constexpr int BLK_SCRATCH = 80;                    // doubles per scratch line: SU[24], SV[24], 32 dump slots (lanes 32..63); two lines per wave
+__host__ __device__ constexpr int blk_rows_per_lane(int W) { return (W + BLK_CELLS - 1 + 2) / 3; }
+
+template <int W, int KP>
+__global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, const double2 *__restrict__ sval,
+                                                           double2 *__restrict__ grid)
+{
+    const PlaneArgs &a = ga.a;
+    constexpr int D = kernel_poly_degree_c(W);
+    constexpr int L = TILE + W - 1;
+    constexpr int LS = tile_stride(W);
+    constexpr int LL = tile_rows(W) * LS;
+    constexpr int FP = W + BLK_CELLS - 1;  // footprint edge of a block
+    constexpr int NR = blk_rows_per_lane(W);
+    constexpr int G = BLK_CELLS - 1;       // zero guard in front of the kernel values
+    const int BLK_THREADS = int(blockDim.x);  // blk_threads(planes per pass of the plan) <= blk_threads(KP)
+    extern __shared__ double lds[];
+    double *wtab = lds + 2 * ga.kp_alloc * LL;
+    double *scr_all = wtab + W * (D + 1);
+
+    uint32_t item = blockIdx.x;
+    if (item >= a.nwork) return;
+    const WorkItem wi = a.work[item];
+    for (int i = threadIdx.x; i < 2 * KP * LL; i += BLK_THREADS) lds[i] = 0.0;
+    for (int i = threadIdx.x; i < W * (D + 1); i += BLK_THREADS) wtab[i] = a.ktab[i];
+    for (int i = threadIdx.x; i < (BLK_THREADS / 64) * 2 * BLK_SCRATCH; i += BLK_THREADS) scr_all[i] = 0.0;
+
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    double *scr = scr_all + wave * 2 * BLK_SCRATCH;
+    const int b = lane & 15;
+    double c[D + 1];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) c[k] = (b < W && lane < 32) ? a.ktab[b * (D + 1) + k] : 0.0;
+    // cell ownership: lane = 20 g + cc, rows g NR + k
+    const int g = lane / 20, cc = lane - 20 * g;
+    const bool act = g < 3 && cc < FP;
+    // SU[t + G] (lanes 0..15), SV[t + G] at scr + 24 (lanes 16..31); lanes 32..63 write (zeros) to dump slots 48..79
+    const int wslot = lane < 16 ? lane + G : (lane < 32 ? lane + 8 + G : lane + 16);
+    __syncthreads();
+
+    const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
+    const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
+    const double shift = 1.0 - 0.5 * double(W);
+
+    double are[NR][KP], aim[NR][KP];
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+        for (int p = 0; p < KP; ++p) are[k][p] = aim[k][p] = 0.0;
+
+    auto flush = [&](int key) {
+        const int r0 = (key >> 8) * BLK_CELLS, c0 = (key & 255) * BLK_CELLS;
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int r = g * NR + k;
+                if (r < FP) {
+                    const int off = (r0 + r) * LS + c0 + cc;
+#pragma unroll
+                    for (int p = 0; p < KP; ++p) {
+#ifndef BLK_NOFLUSH
+                        unsafeAtomicAdd(&lds[(2 * p) * LL + off], are[k][p]);
+                        unsafeAtomicAdd(&lds[(2 * p + 1) * LL + off], aim[k][p]);
+#else
+                        if (are[k][p] == 123.456) lds[off] = aim[k][p];
+#endif
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+#pragma unroll
+            for (int p = 0; p < KP; ++p) are[k][p] = aim[k][p] = 0.0;
+    };
+
+    // this wave's contiguous share of the chunk, taken 64 visibilities at a time: lane i loads the record of
+    // visibility base + i and does the per-visibility scalar work (position, plane weights) for it -- 64 at once,
+    // the next batch's loads in flight -- and the wave then walks the batch with v_readlane broadcasts.
+    const uint32_t n = wi.end - wi.begin;
+    const uint32_t NW = uint32_t(BLK_THREADS) / 64;
+    const uint32_t j0 = wi.begin + uint32_t((uint64_t(n) * uint32_t(wave)) / NW);
+    const uint32_t j1 = wi.begin + uint32_t((uint64_t(n) * uint32_t(wave + 1)) / NW);
+    auto bcast = [](double v, int i) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), i), hi = __builtin_amdgcn_readlane(__double2hiint(v), i);
+        return __hiloint2double(hi, lo);
+    };
+    int cur = -1;
+    uint32_t jl = j0 + uint32_t(lane);
+    bool lvalid = jl < j1;
+    double npu = lvalid ? a.pu[jl] : 0.0, npv = lvalid ? a.pv[jl] : 0.0, npw = (lvalid && a.do_w) ? a.pw[jl] : 0.0;
+    double2 nval = lvalid ? sval[jl] : make_double2(0.0, 0.0);
+    for (uint32_t base = j0; base < j1; base += 64) {
+        const double pu = npu, pv = npv, pw = npw;
+        const double2 val = nval;
+        const bool valid = lvalid;
+        jl += 64;
+        lvalid = jl < j1;
+        npu = lvalid ? a.pu[jl] : 0.0;
+        npv = lvalid ? a.pv[jl] : 0.0;
+        npw = (lvalid && a.do_w) ? a.pw[jl] : 0.0;
+        nval = lvalid ? sval[jl] : make_double2(0.0, 0.0);
+        // per lane = per visibility of the batch
+        const double fu = floor(pu + shift), fv = floor(pv + shift);
+        const double zuv = 2.0 * ((pu + shift) - fu) - 1.0, zvv = 2.0 * ((pv + shift) - fv) - 1.0;
+        const int lu = wrap_once((int)fu, a.nu) - bu, lv = wrap_once((int)fv, a.nv) - bv;
+        double vrv[KP], viv[KP];
+        bool touch = false;
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            const double kw = valid ? plane_weight_of<W, D>(a, a.plane + p, ga.coefk[p], pw, wtab) : 0.0;
+            touch = touch || (kw != 0.0);
+            vrv[p] = val.x * kw;
+            viv[p] = val.y * kw;
+        }
+        (void)touch;  // a visibility that touches no plane of the group carries zero values: it is walked like the others
+        const int keyv = (lu << 8) | lv;  // lu, lv in [0, 32)
+        const int nb = int(min(uint32_t(64), j1 - base));
+        // Two-stage software pipeline over the batch: stage A(i) evaluates the kernel values of visibility i and
+        // writes them to scratch line i & 1; stage B(i) reads them back and accumulates.  A(i + 1) is issued between
+        // the reads and the FMAs of B(i) -- different scratch lines, so the Horner chain fills the LDS latency.
+        auto stage_a = [&](int i) {
+            const double zu = bcast(zuv, i), zv = bcast(zvv, i);
+            const double kval = horner<D>(c, lane < 16 ? zu : zv);
+            scr[(i & 1) * BLK_SCRATCH + wslot] = kval;  // lanes >= 32 write zeros into their own spare slots
+        };
+        stage_a(0);
+        for (int i = 0; i < nb; ++i) {
+            const int kk = __builtin_amdgcn_readlane(keyv, i);
+            const int slu = kk >> 8, slv = kk & 255;
+            const int key = ((slu >> 2) << 8) | (slv >> 2);
+            if (key != cur) {
+                if (cur >= 0) flush(cur);
+                cur = key;
+            }
+            const double *sc = scr + (i & 1) * BLK_SCRATCH;
+            const int du = slu & 3, dv = slv & 3;
+            const double kvc = sc[24 + cc - dv + G];
+            const double *su = sc + (g * NR - du + G);
+            double kuv[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) kuv[k] = su[k];
+            stage_a((i + 1) & 63);  // unconditional (one basic block); past the batch end it rewrites a line nobody reads
+            double vr[KP], vi[KP];
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                vr[p] = bcast(vrv[p], i);
+                vi[p] = bcast(viv[p], i);
+            }
+#ifndef BLK_NOACC
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const double t = kuv[k] * kvc;
+#pragma unroll
+                for (int p = 0; p < KP; ++p) {
+                    are[k][p] = fma(vr[p], t, are[k][p]);
+                    aim[k][p] = fma(vi[p], t, aim[k][p]);
+                }
+            }
+#else
+            are[0][0] += kvc * kuv[0] * vr[0] * vi[KP - 1];
+#endif
+        }
+    }
+    if (cur >= 0) flush(cur);
+    __syncthreads();
+    for (int k = 0; k < KP; ++k) {
+        double *gp = reinterpret_cast<double *>(grid + size_t(k) * ga.plane_stride);
+        const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
+        for (int i = threadIdx.x; i < L * L; i += BLK_THREADS) {
+            const int la = i / L, lb = i - la * L;
+            const double re = lre[la * LS + lb], im = lim[la * LS + lb];
+            if (re != 0.0 || im != 0.0) {
+                int gu = bu + la, gv = bv + lb;
+                gu = gu >= a.nu ? gu % a.nu : gu;
+                gv = gv >= a.nv ? gv % a.nv : gv;
+                const size_t o = (size_t(gu) * size_t(a.nv) + size_t(gv)) * 2;
+                unsafeAtomicAdd(&gp[o], re);
+                unsafeAtomicAdd(&gp[o + 1], im);
+            }
+        }
+    }
+}
+
 template <int W, int KP>
 __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const double2 *__restrict__ grid,
                                                            double2 *__restrict__ sacc)

@@ -33,6 +33,8 @@ struct MapArgs {
     int nu, nv;
     int ntv;          // tiles along v
     int key_planes;   // 1: sort key = tile; P > 1: key = tile * P + first plane (wide fields, ES-kernel planes)
+    int key_sub;      // 64: the key carries the 4 x 4-cell block of the footprint origin inside its tile in its low 6 bits
+                      // (run order of the register-footprint scatter, k_grid_blk); 1: no sub-key
     double shift;     // 1 - W/2
     int W;
     int do_w;
