@@ -262,7 +262,7 @@ def main():
                 "workload": wl, "bands": world, "w_scheme": "polynomial planes" if info["wmode"] == 1 else "ES-kernel planes", "vis_per_band": int(case["uvw"].shape[0] * case["freq"].size),
                 "active_vis_per_band": int(g.nactive), "image": [nx, ny], "epsilon": args.epsilon,
                 "grid": [info["nu"], info["nv"]], "occupied_rows": info["occ_rows"], "w_planes": info["nplanes"],
-                "kernel_support": info["W"], "plane_transform": ("own row FFT" if info["fft_mode"] & 1 else "rocFFT rows") +
+                "kernel_support": info["W"], "scatter": "register footprint (k_grid_blk)" if info["scatter_mode"] == 1 else "diagonal walk (k_grid_mp)", "plane_transform": ("own row FFT" if info["fft_mode"] & 1 else "rocFFT rows") +
                 (" + fused second axis" if info["fft_mode"] & 2 else
                  (" + own second axis (unfused)" if info["fft_mode"] & 4 else " + rocFFT second axis")),
                 "sigma": info["sigma"], "parallelism": f"band-per-gpu x{world}" + (f" + 1 RCCL sum-to-root of the image per {reduce_every} applies" if use_reduce else
@@ -281,8 +281,24 @@ def main():
                                        for s in per_launch if stages[s][1]},
             },
         }
-        if dom == "grid":
-            # The scatter kernel is bound by the LDS f64-atomic pipe, not by HBM:
+        if dom == "grid" and info["scatter_mode"] == 1:
+            # Register-footprint scatter: no LDS atomic per tap; what a visibility costs is f64
+            # VALU work -- per held cell one product and 2 FMAs per plane, NR cells per lane, plus the 13-step Horner
+            # chain of the kernel values -- at 4 cycles per wave64 f64 instruction on each of the 1024 SIMDs.
+            out["roofline"]["kernel"] = "k_grid_blk"
+            ngroups = -(-info["nplanes"] // 4)
+            kp = info["nplanes"] / ngroups
+            nr = -(-(info["W"] + 3) // 3)
+            f64_ops = nr * (1 + 2 * kp) + 13
+            floor_ms = g.nactive * f64_ops * 4 / (256 * 4) / 2.4e9 * 1e3
+            out["roofline"]["limiter"] = {
+                "bound": "valu_f64", "f64_wave_instr_per_vis": f64_ops, "cycles_per_instr": 4, "simds": 1024,
+                "clock_ghz": 2.4, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
+                "note": "counted f64 FMA/MUL only; rocprofv3 SQ counters (profiles/) give 107 VALU instructions per "
+                        "visibility and ~50 % VALU-busy, the rest is LDS flush + tile load/store phases",
+            }
+        elif dom == "grid":
+            # The diagonal-walk scatter is bound by the LDS f64-atomic pipe, not by HBM:
             # 2*16*16 ds_add_f64 lane-operations per visibility and plane, ~12 cycles per wave-instruction.
             ngroups = -(-info["nplanes"] // 4)
             winstr = g.nactive * (info["nplanes"] / ngroups) * 512 / 64          # wave-instructions per launch

@@ -108,6 +108,10 @@ typedef struct pfbhip_gridder_info {
      * FFT with separate pad / crop kernels (the doubled sizes 20480, 24576); neither bit 1 nor 2: rocFFT */
     int32_t fft_mode;
     int32_t screen_poly;   /* coefficients of the n-1 polynomial of the fused w-screen (0: closed form) */
+    /* scatter kernel: 1 = register-footprint form (k_grid_blk: visibilities sorted by tile and 4 x 4-cell block, LDS
+     * atomics only when the block changes), 0 = diagonal-walk form (k_grid_mp: LDS atomics per tap) */
+    int32_t scatter_mode;
+    int32_t reserved0;
 } pfbhip_gridder_info;
 
 int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw_host /* (nrow,3) */,

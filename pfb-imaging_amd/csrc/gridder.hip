@@ -622,12 +622,10 @@ struct pfbhip_gridder {
         hipLaunchKernelGGL((k_grid_mp<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga, sval,
                            d_grid.p);
     }
-    template <int W>
-    size_t lds_bytes_blk(int kp_alloc) const
+    template <int W, int KP>
+    size_t lds_bytes_blk() const
     {
-        constexpr int D = kernel_poly_degree_c(W);
-        return (size_t(2) * size_t(kp_alloc) * tile_rows(W) * tile_stride(W) + size_t(W) * (D + 1) +
-                size_t(blk_threads(kp_alloc) / 64) * 2 * BLK_SCRATCH) * sizeof(double);
+        return (size_t(2) * KP * blk_tile_rows(W) * blk_stride(W, KP) + blk_fixed_doubles(W, blk_threads(kp_max) / 64)) * sizeof(double);
     }
     template <int W, int KP>
     void launch_grid_blk_wk(const GroupArgs &ga, const double2 *sval)
@@ -635,11 +633,12 @@ struct pfbhip_gridder {
         static bool attr_set = false;
         if (!attr_set) {
             PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_blk<W, KP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_blk<W>(KP_MAX))));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_grid_blk<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds_bytes_blk<W>(kp_max), stream, ga, sval,
-                           d_grid.p);
+        const size_t lds = lds_bytes_blk<W, KP>();
+        PFB_REQUIRE(lds <= size_t(160) * 1024, "block scatter needs %zu bytes of LDS", lds);
+        hipLaunchKernelGGL((k_grid_blk<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, sval, d_grid.p);
     }
     bool scatter_blk = true;  // register-footprint scatter (k_grid_blk); PFBHIP_SCATTER=walk selects k_grid_mp
     template <int W>
@@ -1309,6 +1308,8 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     }
     info.fft_mode = (g->rowfft_v.ok ? 1 : 0) | (g->fused ? 2 : 0) | ((!g->fused && g->rowfft_u.ok) ? 4 : 0);
     info.screen_poly = g->fgeom.npoly;
+    info.scatter_mode = g->scatter_blk ? 1 : 0;
+    info.reserved0 = 0;
     g->bstride = size_t(prm.ny) * size_t(info.nu);
     g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
     g->d_accT.alloc(size_t(npix));

@@ -194,6 +194,18 @@ __host__ __device__ constexpr int blk_threads(int KP) { return KP <= 3 ? 768 : 5
 constexpr int BLK_CELLS = 4;                       // block edge in grid cells
 constexpr int BLK_SCRATCH = 80;                    // doubles per scratch line: SU[24], SV[24], 32 dump slots (lanes 32..63); two lines per wave
 __host__ __device__ constexpr int blk_rows_per_lane(int W) { return (W + BLK_CELLS - 1 + 2) / 3; }
+// LDS tile of the block kernel: TILE + W - 1 rows.  A flush instruction touches 3 adjacent rows x (W + 3) columns; a row
+// stride of +-11 doubles mod 32 spreads them over the 64 banks two-deep (the minimum for 60 doubles); an even stride
+// puts two of the three rows on the same banks.  The wide stride is used when the tiles of KP planes still fit.
+__host__ __device__ constexpr int blk_tile_rows(int W) { return TILE + W - 1; }
+__host__ __device__ constexpr size_t blk_fixed_doubles(int W, int waves) { return size_t(W) * (kernel_poly_degree_c(W) + 1) + size_t(waves) * 2 * BLK_SCRATCH; }
+__host__ __device__ constexpr int blk_stride(int W, int KP)
+{
+    const int L = TILE + W - 1;
+    const int wide = L <= 43 ? 43 : 53;
+    const size_t bytes = (size_t(2) * KP * L * wide + blk_fixed_doubles(W, 12)) * sizeof(double);
+    return bytes <= size_t(160) * 1024 ? wide : ((L & 1) ? L + 1 : L);
+}
 
 template <int W, int KP>
 __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, const double2 *__restrict__ sval,
@@ -202,14 +214,14 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
     const PlaneArgs &a = ga.a;
     constexpr int D = kernel_poly_degree_c(W);
     constexpr int L = TILE + W - 1;
-    constexpr int LS = tile_stride(W);
-    constexpr int LL = tile_rows(W) * LS;
+    constexpr int LS = blk_stride(W, KP);
+    constexpr int LL = blk_tile_rows(W) * LS;
     constexpr int FP = W + BLK_CELLS - 1;  // footprint edge of a block
     constexpr int NR = blk_rows_per_lane(W);
     constexpr int G = BLK_CELLS - 1;       // zero guard in front of the kernel values
     const int BLK_THREADS = int(blockDim.x);  // blk_threads(planes per pass of the plan) <= blk_threads(KP)
     extern __shared__ double lds[];
-    double *wtab = lds + 2 * ga.kp_alloc * LL;
+    double *wtab = lds + 2 * KP * LL;  // own layout: the tiles of this launch's KP planes, then the tables
     double *scr_all = wtab + W * (D + 1);
 
     uint32_t item = blockIdx.x;
@@ -225,7 +237,7 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
     double c[D + 1];
 #pragma unroll
     for (int k = 0; k <= D; ++k) c[k] = (b < W && lane < 32) ? a.ktab[b * (D + 1) + k] : 0.0;
-    // cell ownership: lane = 20 g + cc, rows g NR + k
+    // cell ownership: lane = 20 g + cc, rows 3 k + g
     const int g = lane / 20, cc = lane - 20 * g;
     const bool act = g < 3 && cc < FP;
     // SU[t + G] (lanes 0..15), SV[t + G] at scr + 24 (lanes 16..31); lanes 32..63 write (zeros) to dump slots 48..79
@@ -247,7 +259,7 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
         if (act) {
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
-                const int r = g * NR + k;
+                const int r = 3 * k + g;
                 if (r < FP) {
                     const int off = (r0 + r) * LS + c0 + cc;
 #pragma unroll
@@ -330,10 +342,10 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
             const double *sc = scr + (i & 1) * BLK_SCRATCH;
             const int du = slu & 3, dv = slv & 3;
             const double kvc = sc[24 + cc - dv + G];
-            const double *su = sc + (g * NR - du + G);
+            const double *su = sc + (g - du + G);
             double kuv[NR];
 #pragma unroll
-            for (int k = 0; k < NR; ++k) kuv[k] = su[k];
+            for (int k = 0; k < NR; ++k) kuv[k] = su[3 * k];
             stage_a((i + 1) & 63);  // unconditional (one basic block); past the batch end it rewrites a line nobody reads
             double vr[KP], vi[KP];
 #pragma unroll
