@@ -1166,6 +1166,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     const char *senv = std::getenv("PFBHIP_SCATTER");
     g->scatter_blk = !(senv != nullptr && std::string(senv) == "walk");
     m.key_sub = (g->scatter_blk && nkeys * 64 < (int64_t(1) << 32) - 2) ? 64 : 1;
+    g->scatter_blk = m.key_sub > 1;  // without the block order in the 32-bit key the runs are ~1 long: the walk kernel is cheaper
     std::vector<WorkItem> work;
     g->work_off.clear();
     g->work_cnt.clear();
