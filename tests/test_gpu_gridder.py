@@ -290,6 +290,24 @@ def test_gridder_cg_matches_oracle_pcg():
     g.close()
 
 
+@pytest.mark.parametrize("eps,widen,zscale", [(1e-7, 8.0, 0.02), (1e-4, 30.0, 0.5), (1e-10, 8.0, 0.02)])
+def test_scatter_forms_agree(eps, widen, zscale, monkeypatch):
+    """The register-footprint scatter (default: block-sorted visibilities, footprints accumulated in registers) and the
+    diagonal-walk scatter (PFBHIP_SCATTER=walk) are the same sum in a different order (the tile order of the sort is
+    checked in test_binmap_bit_exact, which runs the default form)."""
+    c = make(nrow=3000, npix=256, widen=widen, zscale=zscale)
+    res = {}
+    for mode in ("block", "walk"):
+        monkeypatch.setenv("PFBHIP_SCATTER", mode)
+        g, kw, mask = gpu_plan(c, epsilon=eps)
+        assert g.info["scatter_mode"] == (1 if mode == "block" else 0)
+        g.set_weights(c["wgt"])
+        res[mode] = (g.vis2dirty(c["vis"], c["wgt"]), g.hessian(c["x"], eta=0.1, wsum=3.0), g.info["W"], g.info["nplanes"])
+        g.close()
+    assert res["block"][2:] == res["walk"][2:]
+    assert rel(res["block"][0], res["walk"][0]) < 1e-9 and rel(res["block"][1], res["walk"][1]) < 1e-9
+
+
 def test_gridder_power_method_matches_oracle():
     """Spectral norm of the exact Hessian: the device-resident iteration against the numpy restatement
     (opt/power_method.py:40-93) around the oracle gridder, and through opt.power_method(g.hessian, ...)."""
