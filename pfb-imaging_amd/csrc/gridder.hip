@@ -488,6 +488,12 @@ struct pfbhip_gridder {
     DevBuf<uint32_t> d_src;
     DevBuf<WorkItem> d_work;
     std::vector<size_t> work_off, work_cnt;  // per group of kp_max planes: slice of d_work
+    // the same work split by tile colour (parity of the tile row / column) for the register-footprint scatter, whose tile
+    // flush is a plain read-add-write when no other tile of the launch overlaps: 4 slices per group (empty when the tile
+    // counts are odd -- the periodic wrap would put two tiles of one colour next to each other -- then one slice, all shared)
+    DevBuf<WorkItem> d_work_col;
+    std::vector<size_t> col_off, col_cnt;  // [group * 4 + colour]
+    bool coloured = false;
     // scratch
     DevBuf<double2> d_grid, d_sval, d_sacc, d_vis;
     DevBuf<double> d_wgt, d_swgt, d_img, d_img2, d_beam;
@@ -529,7 +535,7 @@ struct pfbhip_gridder {
     size_t device_bytes() const
     {
         return d_uvw.bytes() + d_fc.bytes() + d_pu.bytes() + d_pv.bytes() + d_pw.bytes() + d_corr.bytes() +
-               d_cfu.bytes() + d_cfv.bytes() + d_cheb.bytes() + d_ktab.bytes() + d_mask.bytes() + d_src.bytes() + d_work.bytes() +
+               d_cfu.bytes() + d_cfv.bytes() + d_cheb.bytes() + d_ktab.bytes() + d_mask.bytes() + d_src.bytes() + d_work.bytes() + d_work_col.bytes() +
                d_grid.bytes() + d_sval.bytes() + d_sacc.bytes() + d_vis.bytes() + d_wgt.bytes() + d_swgt.bytes() +
                d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes() + d_gridB.bytes() +
                d_accT.bytes() + d_occ.bytes();
@@ -647,11 +653,17 @@ struct pfbhip_gridder {
         GroupArgs ga = group_args(plane0, kp);
         if (ga.a.nwork == 0) return;
         if (scatter_blk) {
-            switch (kp) {
-                case 1: launch_grid_blk_wk<W, 1>(ga, sval); break;
-                case 2: launch_grid_blk_wk<W, 2>(ga, sval); break;
-                case 3: launch_grid_blk_wk<W, 3>(ga, sval); break;
-                default: launch_grid_blk_wk<W, 4>(ga, sval); break;
+            const size_t grp = work_off.size() > 1 ? size_t(plane0 / kp_max) : 0;
+            for (int col = 0; col < 4; ++col) {  // one launch per tile colour (see k_grid_blk's flush)
+                ga.a.work = d_work_col.p + col_off[grp * 4 + size_t(col)];
+                ga.a.nwork = uint32_t(col_cnt[grp * 4 + size_t(col)]);
+                if (ga.a.nwork == 0) continue;
+                switch (kp) {
+                    case 1: launch_grid_blk_wk<W, 1>(ga, sval); break;
+                    case 2: launch_grid_blk_wk<W, 2>(ga, sval); break;
+                    case 3: launch_grid_blk_wk<W, 3>(ga, sval); break;
+                    default: launch_grid_blk_wk<W, 4>(ga, sval); break;
+                }
             }
             return;
         }
@@ -1226,6 +1238,42 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     if (g->work_off.empty()) {
         g->work_off.push_back(0);
         g->work_cnt.push_back(0);
+    }
+    {
+        // colour slices of every group's list (LPT order kept inside a slice); chunks of a tile that has several in the
+        // slice are flagged shared (pad = 1) and keep the atomic flush
+        const int64_t ntu_c = ceil_div(info.nu, TILE);
+        g->coloured = g->scatter_blk && (ntu_c % 2 == 0) && (m.ntv % 2 == 0) && info.nu % TILE == 0 && info.nv % TILE == 0;
+        std::vector<WorkItem> wcol;
+        wcol.reserve(work.size());
+        g->col_off.clear();
+        g->col_cnt.clear();
+        std::vector<uint32_t> seen;
+        for (size_t grp = 0; grp < g->work_off.size(); ++grp) {
+            const size_t b0 = g->work_off[grp], b1 = b0 + g->work_cnt[grp];
+            seen.assign(size_t(info.ntiles), 0);
+            for (size_t i = b0; i < b1; ++i) seen[work[i].tile]++;
+            for (int col = 0; col < 4; ++col) {
+                g->col_off.push_back(wcol.size());
+                for (size_t i = b0; i < b1; ++i) {
+                    const uint32_t tu = work[i].tile / uint32_t(m.ntv), tv = work[i].tile % uint32_t(m.ntv);
+                    const int c = g->coloured ? int((tu & 1u) * 2u + (tv & 1u)) : 0;
+                    if (c != col) continue;
+                    WorkItem w = work[i];
+                    w.pad = (!g->coloured || seen[w.tile] > 1) ? 1u : 0u;
+                    wcol.push_back(w);
+                }
+                g->col_cnt.push_back(wcol.size() - g->col_off.back());
+            }
+        }
+        if (g->col_off.empty()) {
+            g->col_off.assign(4, 0);
+            g->col_cnt.assign(4, 0);
+        }
+        g->d_work_col.alloc(std::max<size_t>(wcol.size(), 1));
+        if (!wcol.empty())
+            PFB_HIP(hipMemcpyAsync(g->d_work_col.p, wcol.data(), wcol.size() * sizeof(WorkItem), hipMemcpyHostToDevice, st));
+        PFB_HIP(hipStreamSynchronize(st));  // wcol is a local
     }
     info.nwork = int64_t(work.size());
     g->d_work.alloc(std::max<size_t>(work.size(), 1));

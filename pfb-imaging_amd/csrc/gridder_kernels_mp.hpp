@@ -370,8 +370,15 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
     }
     if (cur >= 0) flush(cur);
     __syncthreads();
+    // Tile -> uv-grid.  The (TILE + W - 1)^2 regions of tiles two apart in each direction are disjoint (W - 1 < TILE), so
+    // within one launch of a single COLOUR (tile-row parity, tile-column parity) nobody else touches this region: a plain
+    // coalesced read-add-write of whole complex cells.  Device-scope f64 atomics execute at the memory side, one 8-byte
+    // operation per transaction: flushing every tile of C2 that way takes 2.7 ms per launch, the plain form 0.5 ms.
+    // Work items flagged `shared` (several chunks of one tile in the same launch, or a plan without colours) keep the atomics.
+    const bool shared = wi.pad != 0;
     for (int k = 0; k < KP; ++k) {
-        double *gp = reinterpret_cast<double *>(grid + size_t(k) * ga.plane_stride);
+        double2 *gk = grid + size_t(k) * ga.plane_stride;
+        double *gp = reinterpret_cast<double *>(gk);
         const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
         for (int i = threadIdx.x; i < L * L; i += BLK_THREADS) {
             const int la = i / L, lb = i - la * L;
@@ -380,9 +387,16 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
                 int gu = bu + la, gv = bv + lb;
                 gu = gu >= a.nu ? gu % a.nu : gu;
                 gv = gv >= a.nv ? gv % a.nv : gv;
-                const size_t o = (size_t(gu) * size_t(a.nv) + size_t(gv)) * 2;
-                unsafeAtomicAdd(&gp[o], re);
-                unsafeAtomicAdd(&gp[o + 1], im);
+                const size_t o = size_t(gu) * size_t(a.nv) + size_t(gv);
+                if (shared) {
+                    unsafeAtomicAdd(&gp[2 * o], re);
+                    unsafeAtomicAdd(&gp[2 * o + 1], im);
+                } else {
+                    double2 v = gk[o];
+                    v.x += re;
+                    v.y += im;
+                    gk[o] = v;
+                }
             }
         }
     }
