@@ -376,29 +376,58 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
     // operation per transaction: flushing every tile of C2 that way takes 2.7 ms per launch, the plain form 0.5 ms.
     // Work items flagged `shared` (several chunks of one tile in the same launch, or a plan without colours) keep the atomics.
     const bool shared = wi.pad != 0;
-    for (int k = 0; k < KP; ++k) {
-        double2 *gk = grid + size_t(k) * ga.plane_stride;
-        double *gp = reinterpret_cast<double *>(gk);
-        const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
-        for (int i = threadIdx.x; i < L * L; i += BLK_THREADS) {
-            const int la = i / L, lb = i - la * L;
-            const double re = lre[la * LS + lb], im = lim[la * LS + lb];
-            if (re != 0.0 || im != 0.0) {
-                int gu = bu + la, gv = bv + lb;
-                gu = gu >= a.nu ? gu % a.nu : gu;
-                gv = gv >= a.nv ? gv % a.nv : gv;
-                const size_t o = size_t(gu) * size_t(a.nv) + size_t(gv);
-                if (shared) {
-                    unsafeAtomicAdd(&gp[2 * o], re);
-                    unsafeAtomicAdd(&gp[2 * o + 1], im);
-                } else {
-                    double2 v = gk[o];
-                    v.x += re;
-                    v.y += im;
-                    gk[o] = v;
+    if (shared) {
+        for (int k = 0; k < KP; ++k) {
+            double *gp = reinterpret_cast<double *>(grid + size_t(k) * ga.plane_stride);
+            const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
+            for (int i = threadIdx.x; i < L * L; i += BLK_THREADS) {
+                const int la = i / L, lb = i - la * L;
+                const double re = lre[la * LS + lb], im = lim[la * LS + lb];
+                if (re != 0.0 || im != 0.0) {
+                    int gu = bu + la, gv = bv + lb;
+                    gu = gu >= a.nu ? gu % a.nu : gu;
+                    gv = gv >= a.nv ? gv % a.nv : gv;
+                    const size_t o = (size_t(gu) * size_t(a.nv) + size_t(gv)) * 2;
+                    unsafeAtomicAdd(&gp[o], re);
+                    unsafeAtomicAdd(&gp[o + 1], im);
                 }
             }
         }
+        return;
+    }
+    // all loads of the thread's cells first (a load -> add -> store chain per cell would expose the HBM latency once per
+    // cell: ~9 cells per thread), then the stores
+    constexpr int NJ = (L * L + 511) / 512;  // cells per thread and plane at the smallest workgroup
+    size_t off[NJ];
+    int lo[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = int(threadIdx.x) + j * BLK_THREADS;
+        const int la = i / L, lb = i - la * L;
+        int gu = bu + la, gv = bv + lb;
+        gu = gu >= a.nu ? gu % a.nu : gu;
+        gv = gv >= a.nv ? gv % a.nv : gv;
+        off[j] = size_t(gu) * size_t(a.nv) + size_t(gv);
+        lo[j] = i < L * L ? la * LS + lb : -1;
+    }
+    double2 v[KP][NJ];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const double2 *gk = grid + size_t(k) * ga.plane_stride;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (lo[j] >= 0) v[k][j] = gk[off[j]];
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        double2 *gk = grid + size_t(k) * ga.plane_stride;
+        const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (lo[j] >= 0) {
+                const double re = lre[lo[j]], im = lim[lo[j]];
+                if (re != 0.0 || im != 0.0) gk[off[j]] = make_double2(v[k][j].x + re, v[k][j].y + im);
+            }
     }
 }
 
