@@ -450,19 +450,36 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
     const WorkItem wi = a.work[item];
     const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
     const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
-    for (int k = 0; k < kp; ++k) {
-        const double2 *gk = grid + size_t(k) * ga.plane_stride;
-        for (int i = threadIdx.x; i < LL; i += MP_THREADS) {
+    {
+        // every load of the thread's cells (all planes) in flight before the first LDS store: a load -> store chain per
+        // cell exposes the HBM latency once per cell and plane
+        constexpr int NJ = (LL + MP_THREADS - 1) / MP_THREADS;
+        size_t off[NJ];
+        bool in[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int i = int(threadIdx.x) + j * MP_THREADS;
             const int la = i / LS, lb = i - la * LS;
-            double2 v = make_double2(0.0, 0.0);
-            if (la < L && lb < L) {
-                int gu = bu + la, gv = bv + lb;
-                gu = gu >= a.nu ? gu % a.nu : gu;
-                gv = gv >= a.nv ? gv % a.nv : gv;
-                v = gk[size_t(gu) * size_t(a.nv) + size_t(gv)];
-            }
-            tiles[k * LL + i] = v;
+            int gu = bu + la, gv = bv + lb;
+            gu = gu >= a.nu ? gu % a.nu : gu;
+            gv = gv >= a.nv ? gv % a.nv : gv;
+            in[j] = i < LL && la < L && lb < L;
+            off[j] = size_t(gu) * size_t(a.nv) + size_t(gv);
         }
+        double2 v[KP][NJ];
+#pragma unroll
+        for (int k = 0; k < kp; ++k) {
+            const double2 *gk = grid + size_t(k) * ga.plane_stride;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) v[k][j] = in[j] ? gk[off[j]] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < kp; ++k)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int i = int(threadIdx.x) + j * MP_THREADS;
+                if (i < LL) tiles[k * LL + i] = v[k][j];
+            }
     }
     for (int i = threadIdx.x; i < W * (D + 1); i += MP_THREADS) wtab[i] = a.ktab[i];
 
