@@ -227,11 +227,23 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
     uint32_t item = blockIdx.x;
     if (item >= a.nwork) return;
     const WorkItem wi = a.work[item];
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    // (first loads requested before the tile is cleared: their latency hides behind it)
+    // this wave's contiguous share of the chunk, taken 64 visibilities at a time: lane i loads the record of
+    // visibility base + i and does the per-visibility scalar work (position, plane weights) for it -- 64 at once,
+    // the next batch's loads in flight -- and the wave then walks the batch with v_readlane broadcasts.
+    const uint32_t n = wi.end - wi.begin;
+    const uint32_t NW = uint32_t(BLK_THREADS) / 64;
+    const uint32_t j0 = wi.begin + uint32_t((uint64_t(n) * uint32_t(wave)) / NW);
+    const uint32_t j1 = wi.begin + uint32_t((uint64_t(n) * uint32_t(wave + 1)) / NW);
+    uint32_t jl = j0 + uint32_t(lane);
+    bool lvalid = jl < j1;
+    double npu = lvalid ? a.pu[jl] : 0.0, npv = lvalid ? a.pv[jl] : 0.0, npw = (lvalid && a.do_w) ? a.pw[jl] : 0.0;
+    double2 nval = lvalid ? sval[jl] : make_double2(0.0, 0.0);
     for (int i = threadIdx.x; i < 2 * KP * LL; i += BLK_THREADS) lds[i] = 0.0;
     for (int i = threadIdx.x; i < W * (D + 1); i += BLK_THREADS) wtab[i] = a.ktab[i];
     for (int i = threadIdx.x; i < (BLK_THREADS / 64) * 2 * BLK_SCRATCH; i += BLK_THREADS) scr_all[i] = 0.0;
 
-    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     double *scr = scr_all + wave * 2 * BLK_SCRATCH;
     const int b = lane & 15;
     double c[D + 1];
@@ -280,22 +292,11 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
             for (int p = 0; p < KP; ++p) are[k][p] = aim[k][p] = 0.0;
     };
 
-    // this wave's contiguous share of the chunk, taken 64 visibilities at a time: lane i loads the record of
-    // visibility base + i and does the per-visibility scalar work (position, plane weights) for it -- 64 at once,
-    // the next batch's loads in flight -- and the wave then walks the batch with v_readlane broadcasts.
-    const uint32_t n = wi.end - wi.begin;
-    const uint32_t NW = uint32_t(BLK_THREADS) / 64;
-    const uint32_t j0 = wi.begin + uint32_t((uint64_t(n) * uint32_t(wave)) / NW);
-    const uint32_t j1 = wi.begin + uint32_t((uint64_t(n) * uint32_t(wave + 1)) / NW);
     auto bcast = [](double v, int i) {
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), i), hi = __builtin_amdgcn_readlane(__double2hiint(v), i);
         return __hiloint2double(hi, lo);
     };
     int cur = -1;
-    uint32_t jl = j0 + uint32_t(lane);
-    bool lvalid = jl < j1;
-    double npu = lvalid ? a.pu[jl] : 0.0, npv = lvalid ? a.pv[jl] : 0.0, npw = (lvalid && a.do_w) ? a.pw[jl] : 0.0;
-    double2 nval = lvalid ? sval[jl] : make_double2(0.0, 0.0);
     for (uint32_t base = j0; base < j1; base += 64) {
         const double pu = npu, pv = npv, pw = npw;
         const double2 val = nval;
@@ -450,6 +451,13 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
     const WorkItem wi = a.work[item];
     const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
     const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
+    // the first records are requested before the tile: their latency hides behind the tile loads
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = lane & 15, g = lane >> 4;
+    const uint32_t stride = (MP_THREADS / 64) * 4;
+    uint32_t j = wi.begin + wave * 4 + g;
+    bool valid = j < wi.end;
+    double pu = valid ? a.pu[j] : 0.0, pv = valid ? a.pv[j] : 0.0, pw = (valid && a.do_w) ? a.pw[j] : 0.0;
     {
         // every load of the thread's cells (all planes) in flight before the first LDS store: a load -> store chain per
         // cell exposes the HBM latency once per cell and plane
@@ -483,8 +491,6 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
     }
     for (int i = threadIdx.x; i < W * (D + 1); i += MP_THREADS) wtab[i] = a.ktab[i];
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = lane & 15, g = lane >> 4;
     double c[D + 1];
 #pragma unroll
     for (int k = 0; k <= D; ++k) c[k] = b < W ? a.ktab[b * (D + 1) + k] : 0.0;
@@ -492,10 +498,6 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
     __syncthreads();
 
     const double shift = 1.0 - 0.5 * double(W);
-    const uint32_t stride = (MP_THREADS / 64) * 4;
-    uint32_t j = wi.begin + wave * 4 + g;
-    bool valid = j < wi.end;
-    double pu = valid ? a.pu[j] : 0.0, pv = valid ? a.pv[j] : 0.0, pw = (valid && a.do_w) ? a.pw[j] : 0.0;
     for (uint32_t jb = wi.begin + wave * 4; jb < wi.end; jb += stride) {
         const uint32_t jn = j + stride;
         const bool nvalid = jn < wi.end;
