@@ -230,6 +230,9 @@ def main():
 
     if rank == 0:
         b_apply, per_launch = algorithmic_bytes(info, nx, ny, case["uvw"].shape[0], g.nactive)
+        # the register-footprint scatter runs one launch per tile colour: each moves a quarter of the pass's bytes
+        nsl = max(int(info["scatter_launches"]), 1)
+        per_launch["grid"] /= nsl
         dom = max((s for s in stages if s in per_launch and stages[s][1]), key=lambda s: stages[s][0])
         dom_ms, dom_calls = stages[dom]
         avg_ms = dom_ms / max(dom_calls, 1)
@@ -262,7 +265,7 @@ def main():
                 "workload": wl, "bands": world, "w_scheme": "polynomial planes" if info["wmode"] == 1 else "ES-kernel planes", "vis_per_band": int(case["uvw"].shape[0] * case["freq"].size),
                 "active_vis_per_band": int(g.nactive), "image": [nx, ny], "epsilon": args.epsilon,
                 "grid": [info["nu"], info["nv"]], "occupied_rows": info["occ_rows"], "w_planes": info["nplanes"],
-                "kernel_support": info["W"], "scatter": "register footprint (k_grid_blk)" if info["scatter_mode"] == 1 else "diagonal walk (k_grid_mp)", "plane_transform": ("own row FFT" if info["fft_mode"] & 1 else "rocFFT rows") +
+                "kernel_support": info["W"], "scatter": (f"register footprint (k_grid_blk), {info['scatter_launches']} launch(es) per pass" if info["scatter_mode"] == 1 else "diagonal walk (k_grid_mp)"), "plane_transform": ("own row FFT" if info["fft_mode"] & 1 else "rocFFT rows") +
                 (" + fused second axis" if info["fft_mode"] & 2 else
                  (" + own second axis (unfused)" if info["fft_mode"] & 4 else " + rocFFT second axis")),
                 "sigma": info["sigma"], "parallelism": f"band-per-gpu x{world}" + (f" + 1 RCCL sum-to-root of the image per {reduce_every} applies" if use_reduce else
@@ -290,10 +293,10 @@ def main():
             kp = info["nplanes"] / ngroups
             nr = -(-(info["W"] + 3) // 3)
             f64_ops = nr * (1 + 2 * kp) + 13
-            floor_ms = g.nactive * f64_ops * 4 / (256 * 4) / 2.4e9 * 1e3
+            floor_ms = g.nactive * f64_ops * 4 / (256 * 4) / 2.4e9 * 1e3 / nsl   # per launch
             out["roofline"]["limiter"] = {
                 "bound": "valu_f64", "f64_wave_instr_per_vis": f64_ops, "cycles_per_instr": 4, "simds": 1024,
-                "clock_ghz": 2.4, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
+                "clock_ghz": 2.4, "launches_per_pass": nsl, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
                 "note": "counted f64 FMA/MUL only; rocprofv3 SQ counters (profiles/) give 107 VALU instructions per "
                         "visibility and ~50 % VALU-busy, the rest is LDS flush + tile load/store phases",
             }

@@ -111,7 +111,9 @@ typedef struct pfbhip_gridder_info {
     /* scatter kernel: 1 = register-footprint form (k_grid_blk: visibilities sorted by tile and 4 x 4-cell block, LDS
      * atomics only when the block changes), 0 = diagonal-walk form (k_grid_mp: LDS atomics per tap) */
     int32_t scatter_mode;
-    int32_t reserved0;
+    /* launches of the scatter per pass over the planes: 4 = one per tile colour (tile-row / tile-column parity), whose
+     * tile flush is a plain read-add-write because no two tiles of a colour overlap; 1 = one launch, atomic flush */
+    int32_t scatter_launches;
 } pfbhip_gridder_info;
 
 int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw_host /* (nrow,3) */,

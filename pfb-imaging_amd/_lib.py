@@ -38,7 +38,7 @@ class GridderInfo(ct.Structure):
         ("W", i32), ("tile", i32), ("beta", f64), ("sigma", f64), ("wmin", f64), ("dw", f64),
         ("nshift", f64), ("lshift", f64), ("mshift", f64), ("kernel_eps", f64),
         ("wmode", i32), ("occ_rows", i32), ("wcenter", f64), ("whalf", f64), ("device_bytes", ct.c_size_t),
-        ("fft_mode", i32), ("screen_poly", i32), ("scatter_mode", i32), ("reserved0", i32),
+        ("fft_mode", i32), ("screen_poly", i32), ("scatter_mode", i32), ("scatter_launches", i32),
     ]
 
     def asdict(self):

@@ -658,21 +658,25 @@ struct pfbhip_gridder {
                 ga.a.work = d_work_col.p + col_off[grp * 4 + size_t(col)];
                 ga.a.nwork = uint32_t(col_cnt[grp * 4 + size_t(col)]);
                 if (ga.a.nwork == 0) continue;
+                timer.begin(0);
                 switch (kp) {
                     case 1: launch_grid_blk_wk<W, 1>(ga, sval); break;
                     case 2: launch_grid_blk_wk<W, 2>(ga, sval); break;
                     case 3: launch_grid_blk_wk<W, 3>(ga, sval); break;
                     default: launch_grid_blk_wk<W, 4>(ga, sval); break;
                 }
+                timer.end();
             }
             return;
         }
+        timer.begin(0);
         switch (kp) {
             case 1: launch_grid_mp_wk<W, 1>(ga, sval); break;
             case 2: launch_grid_mp_wk<W, 2>(ga, sval); break;
             case 3: launch_grid_mp_wk<W, 3>(ga, sval); break;
             default: launch_grid_mp_wk<W, 4>(ga, sval); break;
         }
+        timer.end();
     }
     template <int W, int KP>
     void launch_degrid_mp_wk(const GroupArgs &ga, double2 *sacc)
@@ -736,10 +740,8 @@ struct pfbhip_gridder {
                     PFB_HIP(hipMemsetAsync(d_grid.p + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv), 0,
                                            size_t(sp.nrows) * size_t(info.nv) * sizeof(double2), stream));
             timer.end();
-            timer.begin(0);
-            PFB_W_DISPATCH(launch_grid_mp_w, p0, kp, sval);
+            PFB_W_DISPATCH(launch_grid_mp_w, p0, kp, sval);  // stage 0, timed per kernel launch inside
             PFB_HIP(hipGetLastError());
-            timer.end();
             for (int k = 0; k < kp; ++k) {
                 const int p = p0 + k;
                 fft_rows_A(false, k);
@@ -1275,6 +1277,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             PFB_HIP(hipMemcpyAsync(g->d_work_col.p, wcol.data(), wcol.size() * sizeof(WorkItem), hipMemcpyHostToDevice, st));
         PFB_HIP(hipStreamSynchronize(st));  // wcol is a local
     }
+    info.scatter_launches = (g->scatter_blk && g->coloured) ? 4 : 1;
     info.nwork = int64_t(work.size());
     g->d_work.alloc(std::max<size_t>(work.size(), 1));
     if (!work.empty())
@@ -1358,7 +1361,6 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     info.fft_mode = (g->rowfft_v.ok ? 1 : 0) | (g->fused ? 2 : 0) | ((!g->fused && g->rowfft_u.ok) ? 4 : 0);
     info.screen_poly = g->fgeom.npoly;
     info.scatter_mode = g->scatter_blk ? 1 : 0;
-    info.reserved0 = 0;
     g->bstride = size_t(prm.ny) * size_t(info.nu);
     g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
     g->d_accT.alloc(size_t(npix));
