@@ -139,6 +139,12 @@ def main():
                     help="band reduce (RCCL sum-to-root) every this many applies; 0 = once per timed region")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON of rank 0: native libraries (RCCL prints a version banner on fd 1 when
+    # a communicator is created) write to stderr for the lifetime of the process, the JSON goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from pfb_imaging_amd import _lib
     from pfb_imaging_amd._lib import DeviceArray
     from pfb_imaging_amd.parallel import BandComm
@@ -316,7 +322,8 @@ def main():
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mvis/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     comm.barrier()
     g.close()
     comm.close()
