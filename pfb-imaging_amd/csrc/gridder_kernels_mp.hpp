@@ -276,12 +276,8 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
                     const int off = (r0 + r) * LS + c0 + cc;
 #pragma unroll
                     for (int p = 0; p < KP; ++p) {
-#ifndef BLK_NOFLUSH
                         unsafeAtomicAdd(&lds[(2 * p) * LL + off], are[k][p]);
                         unsafeAtomicAdd(&lds[(2 * p + 1) * LL + off], aim[k][p]);
-#else
-                        if (are[k][p] == 123.456) lds[off] = aim[k][p];
-#endif
                     }
                 }
             }
@@ -354,7 +350,6 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
                 vr[p] = bcast(vrv[p], i);
                 vi[p] = bcast(viv[p], i);
             }
-#ifndef BLK_NOACC
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
                 const double t = kuv[k] * kvc;
@@ -364,9 +359,6 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
                     aim[k][p] = fma(vi[p], t, aim[k][p]);
                 }
             }
-#else
-            are[0][0] += kvc * kuv[0] * vr[0] * vi[KP - 1];
-#endif
         }
     }
     if (cur >= 0) flush(cur);
