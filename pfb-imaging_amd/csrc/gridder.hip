@@ -496,6 +496,13 @@ struct pfbhip_gridder {
     bool coloured = false;
     // scratch
     DevBuf<double2> d_grid, d_sval, d_sacc, d_vis;
+    // Hessian applies clear the scatter's planes on a side stream while the degrid half runs: a second plane buffer
+    // (d_grid2) is zeroed there, the scatter waits for it (single-pass plans only; PFBHIP_ASYNC_CLEAR=0 disables)
+    DevBuf<double2> d_grid2;
+    double2 *grid_cur = nullptr;  // the plane buffer the pipeline stages work on (d_grid unless a Hessian switched it)
+    hipStream_t clear_stream = nullptr;
+    hipEvent_t ev_clear = nullptr, ev_start = nullptr;
+    bool async_clear = false, planes_cleared = false, side_clear_pending = false, side_clear_done = false;
     DevBuf<double> d_wgt, d_swgt, d_img, d_img2, d_beam;
     DevBuf<char> d_fftwork;
     DevBuf<double2> d_gridB;  // (ny, nu) transposed / cropped plane
@@ -530,13 +537,16 @@ struct pfbhip_gridder {
         if (fftB_bwd) rocfft_plan_destroy(fftB_bwd);
         if (fft_info) rocfft_execution_info_destroy(fft_info);
         if (stream) (void)hipStreamDestroy(stream);
+        if (clear_stream) (void)hipStreamDestroy(clear_stream);
+        if (ev_clear) (void)hipEventDestroy(ev_clear);
+        if (ev_start) (void)hipEventDestroy(ev_start);
     }
 
     size_t device_bytes() const
     {
         return d_uvw.bytes() + d_fc.bytes() + d_pu.bytes() + d_pv.bytes() + d_pw.bytes() + d_corr.bytes() +
                d_cfu.bytes() + d_cfv.bytes() + d_cheb.bytes() + d_ktab.bytes() + d_mask.bytes() + d_src.bytes() + d_work.bytes() + d_work_col.bytes() +
-               d_grid.bytes() + d_sval.bytes() + d_sacc.bytes() + d_vis.bytes() + d_wgt.bytes() + d_swgt.bytes() +
+               d_grid.bytes() + d_grid2.bytes() + d_sval.bytes() + d_sacc.bytes() + d_vis.bytes() + d_wgt.bytes() + d_swgt.bytes() +
                d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes() + d_gridB.bytes() +
                d_accT.bytes() + d_occ.bytes();
     }
@@ -568,7 +578,7 @@ struct pfbhip_gridder {
     {
         timer.begin(2);
         for (auto &sp : spans) {
-            double2 *rows = d_grid.p + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv);
+            double2 *rows = grid_cur + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv);
             if (rowfft_v.ok) {
                 rowfft_plain(rowfft_v.pl, rows, int(sp.nrows), !forward, stream);
             } else {
@@ -626,7 +636,7 @@ struct pfbhip_gridder {
             attr_set = true;
         }
         hipLaunchKernelGGL((k_grid_mp<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga, sval,
-                           d_grid.p);
+                           grid_cur);
     }
     template <int W, int KP>
     size_t lds_bytes_blk() const
@@ -644,7 +654,7 @@ struct pfbhip_gridder {
         }
         const size_t lds = lds_bytes_blk<W, KP>();
         PFB_REQUIRE(lds <= size_t(160) * 1024, "block scatter needs %zu bytes of LDS", lds);
-        hipLaunchKernelGGL((k_grid_blk<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, sval, d_grid.p);
+        hipLaunchKernelGGL((k_grid_blk<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, sval, grid_cur);
     }
     bool scatter_blk = true;  // register-footprint scatter (k_grid_blk); PFBHIP_SCATTER=walk selects k_grid_mp
     template <int W>
@@ -688,7 +698,7 @@ struct pfbhip_gridder {
             attr_set = true;
         }
         hipLaunchKernelGGL((k_degrid_mp<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga,
-                           d_grid.p, sacc);
+                           grid_cur, sacc);
     }
     template <int W>
     void launch_degrid_mp_w(int plane0, int kp, double2 *sacc)
@@ -722,6 +732,30 @@ struct pfbhip_gridder {
 
     dim3 tgrid(int64_t ncols, int64_t nrows) const { return dim3(uint32_t(ceil_div(ncols, TP)), uint32_t(ceil_div(nrows, TP))); }
 
+    // Clear the second plane buffer on the side stream, starting when this stream reaches the present point (which also
+    // means the previous apply's scatter half, the buffer's last user, has finished).
+    void side_clear()
+    {
+        PFB_HIP(hipEventRecord(ev_start, stream));
+        PFB_HIP(hipStreamWaitEvent(clear_stream, ev_start, 0));
+        double2 *keep = grid_cur;
+        grid_cur = d_grid2.p;
+        clear_planes(int(info.nplanes), clear_stream);
+        grid_cur = keep;
+        PFB_HIP(hipEventRecord(ev_clear, clear_stream));
+        side_clear_pending = false;
+        side_clear_done = true;
+    }
+
+    // zero the occupied rows of the first kp planes of the active plane buffer
+    void clear_planes(int kp, hipStream_t st)
+    {
+        for (int k = 0; k < kp; ++k)
+            for (auto &sp : spans)
+                PFB_HIP(hipMemsetAsync(grid_cur + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv), 0,
+                                       size_t(sp.nrows) * size_t(info.nv) * sizeof(double2), st));
+    }
+
     // sval (tile-sorted, weighted) -> accT, the TRANSPOSED (ny, nx) raw image (before correction)
     // `fin` (fused path only): the last launch writes the finalized image; returns true if it did
     bool grid_all_planes(const double2 *sval, const FusedFinal *fin = nullptr)
@@ -734,12 +768,11 @@ struct pfbhip_gridder {
         bool finalized = false;
         for (int p0 = 0; p0 < info.nplanes; p0 += kp_max) {
             const int kp = int(std::min<int64_t>(kp_max, info.nplanes - p0));
-            timer.begin(5);
-            for (int k = 0; k < kp; ++k)
-                for (auto &sp : spans)
-                    PFB_HIP(hipMemsetAsync(d_grid.p + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv), 0,
-                                           size_t(sp.nrows) * size_t(info.nv) * sizeof(double2), stream));
-            timer.end();
+            if (!planes_cleared) {  // (a Hessian apply may have cleared them on the side stream already)
+                timer.begin(5);
+                clear_planes(kp, stream);
+                timer.end();
+            }
             PFB_W_DISPATCH(launch_grid_mp_w, p0, kp, sval);  // stage 0, timed per kernel launch inside
             PFB_HIP(hipGetLastError());
             for (int k = 0; k < kp; ++k) {
@@ -747,7 +780,7 @@ struct pfbhip_gridder {
                 fft_rows_A(false, k);
                 timer.begin(4);
                 hipLaunchKernelGGL(k_a2b, tgrid(info.nu, prm.ny), dim3(TP, 8), 0, stream, geom, d_occ.p,
-                                   d_grid.p + size_t(k) * plane_stride, d_gridB.p + (fused ? size_t(k) * bstride : 0),
+                                   grid_cur + size_t(k) * plane_stride, d_gridB.p + (fused ? size_t(k) * bstride : 0),
                                    fused ? 0 : 1);
                 PFB_HIP(hipGetLastError());
                 timer.end();
@@ -860,11 +893,12 @@ struct pfbhip_gridder {
                 }
                 timer.begin(3);
                 hipLaunchKernelGGL(k_b2a, tgrid(info.nu, info.nv), dim3(TP, 8), 0, stream, geom, d_occ.p,
-                                   d_gridB.p + (fused ? size_t(k) * bstride : 0), d_grid.p + size_t(k) * plane_stride);
+                                   d_gridB.p + (fused ? size_t(k) * bstride : 0), grid_cur + size_t(k) * plane_stride);
                 PFB_HIP(hipGetLastError());
                 timer.end();
                 fft_rows_A(true, k);
             }
+            if (side_clear_pending) side_clear();
             timer.begin(1);
             PFB_W_DISPATCH(launch_degrid_mp_w, p0, kp, sacc);
             PFB_HIP(hipGetLastError());
@@ -1322,6 +1356,20 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     // ---- scratch + FFT plans ----
     g->plane_stride = size_t(info.nu) * size_t(info.nv);
     g->d_grid.alloc(g->plane_stride * size_t(g->kp_max));
+    g->grid_cur = g->d_grid.p;
+    {
+        const char *aenv = std::getenv("PFBHIP_ASYNC_CLEAR");
+        const bool want = !(aenv != nullptr && aenv[0] == '0');
+        // one pass over the planes (otherwise the buffer is reused inside the apply) and a second buffer of <= 40 GB
+        g->async_clear = want && info.nplanes <= g->kp_max && info.nactive > 0 && g->d_grid.bytes() <= (size_t(40) << 30);
+        if (g->async_clear) {
+            g->d_grid2.alloc(g->plane_stride * size_t(g->kp_max));
+            PFB_HIP(hipStreamCreateWithFlags(&g->clear_stream, hipStreamNonBlocking));
+            PFB_HIP(hipEventCreateWithFlags(&g->ev_clear, hipEventDisableTiming));
+            PFB_HIP(hipEventCreateWithFlags(&g->ev_start, hipEventDisableTiming));
+            PFB_HIP(hipMemsetAsync(g->d_grid2.p, 0, g->d_grid2.bytes(), st));
+        }
+    }
     g->d_img.alloc(size_t(npix));
     g->d_sval.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
     g->d_sacc.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
@@ -1617,13 +1665,32 @@ static void hessian_dev_impl(pfbhip_gridder *g, const double *x_dev, const doubl
     PFB_REQUIRE(g->weights_bound, "call pfbhip_gridder_set_weights before the Hessian");
     hipStream_t st = g->stream;
     const int64_t npix = g->prm.nx * g->prm.ny;
+    const bool side = g->async_clear && g->info.nwork > 0;
+    // the scatter's planes (second buffer) are cleared on the side stream while the GATHER runs (LDS / VALU-bound: the
+    // clear's HBM traffic is free there; next to the row-FFT stages it only takes their bandwidth): see side_clear()
+    g->side_clear_pending = side;
+    g->side_clear_done = false;
     g->prepare_and_degrid(x_dev, beam_dev, g->d_sacc.p);
+    g->side_clear_pending = false;
     g->timer.begin(5);
     if (g->info.nactive)
         hipLaunchKernelGGL(k_scale_sorted, blocks1d(g->info.nactive), dim3(256), 0, st, g->info.nactive, g->d_sacc.p,
                            g->d_swgt.p, g->d_sval.p);
     PFB_HIP(hipGetLastError());
     g->timer.end();
+    if (g->side_clear_done) {
+        PFB_HIP(hipStreamWaitEvent(st, g->ev_clear, 0));
+        g->grid_cur = g->d_grid2.p;
+        g->planes_cleared = true;
+    }
+    struct Restore {  // also on an exception out of the scatter half
+        pfbhip_gridder *g;
+        ~Restore()
+        {
+            g->grid_cur = g->d_grid.p;
+            g->planes_cleared = false;
+        }
+    } restore{g};
     g->grid_and_finalize(g->d_sval.p, beam_dev, wsum > 0.0 ? 1.0 / wsum : 1.0, eta, eta != 0.0 ? x_dev : nullptr, out_dev);
     (void)npix;
 }
