@@ -383,3 +383,36 @@ def test_power_method_on_device():
     betat, bt = power_method(hr.dot, b0.shape, b0=b0, tol=0.0, maxit=20, verbosity=0)
     rbt, rbv, _ = fftconv.power_method(tree_op, b0.shape, b0.copy(), tol=0.0, maxit=20)
     assert abs(betat - rbt) < 1e-11 * abs(rbt) and rel(bt, rbv) < 1e-9
+
+
+def test_power_method_with_communicator():
+    """The band-per-rank form of the power iteration (power_method_dist, opt/power_method.py:178-208): the three dots
+    go through an RCCL all-reduce.  A 1-rank communicator must reproduce the single-process iteration bit for bit."""
+    import ctypes as ct
+
+    from pfb_imaging_amd._lib import PMInfo, cint, f64, i64, lib, check, ptr
+    from pfb_imaging_amd.opt import PrimalDual
+    from pfb_imaging_amd.operators.hessian import HessPSF
+    from pfb_imaging_amd.parallel import BandComm
+
+    psf, psfhat, abspsf, x, beam = _psf_case(nband=2, nx=32, ny=32, nxp=64, nyp=64, seed=7)
+    h = HessPSF(32, 32, abspsf, beam=beam, eta=np.array([0.1, 0.3]))
+    bands, _, local = PrimalDual._hess_bands(h, 2)
+    handles = (ct.c_void_p * 2)(*[b[0]._h for b in bands])
+    nparts = np.array([len(b[1]) for b in bands], dtype=np.int64)
+    psf_slots = np.array([s for b in bands for s in b[1]], dtype=np.int64)
+    beam_slots = np.array([s for b in bands for s in b[2]], dtype=np.int64)
+    scale = np.array([b[3] for b in bands], dtype=np.float64)
+    eta = np.array([b[4] for b in bands], dtype=np.float64)
+    b0 = np.random.default_rng(12).standard_normal(x.shape)
+    comm = BandComm.from_env(transport="rccl", set_device=False)
+    out = []
+    for c in (None, comm._h):
+        b = b0.copy()
+        info = PMInfo()
+        check(lib().pfbhip_psfconv_power_method(handles, i64(2), ptr(nparts), ptr(psf_slots), ptr(beam_slots), ptr(scale),
+                                                ptr(eta), ptr(b), f64(0.0), cint(12), c, ct.byref(info)))
+        out.append((info.beta, info.iters, b))
+    comm.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1] == 12
+    assert np.array_equal(out[0][2], out[1][2])
