@@ -1211,8 +1211,11 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     m.key_planes = plane_sorted ? int(info.nplanes) : 1;
     const int64_t nkeys = info.ntiles * m.key_planes;
     // register-footprint scatter (k_grid_blk): runs of visibilities whose footprint origins share a 4 x 4-cell block
+    // PFBHIP_SCATTER = walk | block forces the kernel; by default the register-footprint form is used when the plan has
+    // enough work items to fill the GPU in each of its four colour launches (decided below, once the work list exists)
     const char *senv = std::getenv("PFBHIP_SCATTER");
-    g->scatter_blk = !(senv != nullptr && std::string(senv) == "walk");
+    const std::string smode = senv != nullptr ? std::string(senv) : std::string("auto");
+    g->scatter_blk = smode != "walk";
     m.key_sub = (g->scatter_blk && nkeys * 64 < (int64_t(1) << 32) - 2) ? 64 : 1;
     g->scatter_blk = m.key_sub > 1;  // without the block order in the 32-bit key the runs are ~1 long: the walk kernel is cheaper
     std::vector<WorkItem> work;
@@ -1274,6 +1277,13 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     if (g->work_off.empty()) {
         g->work_off.push_back(0);
         g->work_cnt.push_back(0);
+    }
+    // Small plans (C1: ~300 work items) run faster on the single-launch walk kernel: four colour launches of a few dozen
+    // workgroups each leave most of the 256 CUs idle.  The block order of the sort is kept either way (any order is valid).
+    {
+        size_t per_pass = work.size();
+        for (size_t c : g->work_cnt) per_pass = std::min(per_pass, c);
+        if (g->scatter_blk && smode != "block" && per_pass < size_t(2048)) g->scatter_blk = false;
     }
     {
         // colour slices of every group's list (LPT order kept inside a slice); chunks of a tile that has several in the

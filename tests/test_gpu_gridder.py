@@ -306,6 +306,11 @@ def test_scatter_forms_agree(eps, widen, zscale, monkeypatch):
         g.close()
     assert res["block"][2:] == res["walk"][2:]
     assert rel(res["block"][0], res["walk"][0]) < 1e-9 and rel(res["block"][1], res["walk"][1]) < 1e-9
+    # left to itself the plan takes the single-launch walk kernel for a problem this small (a few hundred work items)
+    monkeypatch.delenv("PFBHIP_SCATTER")
+    g, kw, mask = gpu_plan(c, epsilon=eps)
+    assert g.info["scatter_mode"] == 0 and g.info["scatter_launches"] == 1 and g.info["nwork"] < 2048
+    g.close()
 
 
 def test_gridder_power_method_matches_oracle():
