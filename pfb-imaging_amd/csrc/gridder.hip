@@ -309,8 +309,10 @@ __global__ void __launch_bounds__(256) k_finalize_img(const double *accT, const 
     out[i] = v;
 }
 
+constexpr int TRANSPOSE_ROWS = 8;  // blockDim.y of the plane transposes (compile-time: the four loads of a thread are then in flight together)
+
 // B (ny, nu) <- A (nu, nv): B[y][u] = A[u][wrap(y - ny/2, nv)] for occupied 32-row blocks of u, 0 elsewhere
-__global__ void k_a2b(ImgGeom g, const uint8_t *occ, const double2 *A, double2 *B, int write_zeros)
+__global__ void __launch_bounds__(TP * TRANSPOSE_ROWS) k_a2b(ImgGeom g, const uint8_t *occ, const double2 *A, double2 *B, int write_zeros)
 {
     __shared__ double2 t[TP][TP + 1];
     const int u0 = blockIdx.x * TP, y0 = blockIdx.y * TP;
@@ -318,7 +320,9 @@ __global__ void k_a2b(ImgGeom g, const uint8_t *occ, const double2 *A, double2 *
     const bool on = occ[blockIdx.x] != 0;
     if (!on && !write_zeros) return;  // the fused second pass treats unoccupied blocks as zero without reading them
     if (on) {
-        for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+#pragma unroll
+        for (int kk = 0; kk < TP / TRANSPOSE_ROWS; ++kk) {
+            const int k = int(threadIdx.y) + kk * TRANSPOSE_ROWS;
             int u = u0 + k, y = y0 + threadIdx.x;
             if (u < g.nu && y < g.ny) {
                 int v = y - hy;
@@ -328,20 +332,24 @@ __global__ void k_a2b(ImgGeom g, const uint8_t *occ, const double2 *A, double2 *
         }
         __syncthreads();
     }
-    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+#pragma unroll
+    for (int kk = 0; kk < TP / TRANSPOSE_ROWS; ++kk) {
+        const int k = int(threadIdx.y) + kk * TRANSPOSE_ROWS;
         int y = y0 + k, u = u0 + threadIdx.x;
         if (u < g.nu && y < g.ny) B[size_t(y) * g.nu + u] = on ? t[threadIdx.x][k] : make_double2(0.0, 0.0);
     }
 }
 
 // A (nu, nv) <- B (ny, nu) for occupied 32-row blocks of u: A[u][v] = B[y(v)][u], 0 where v is outside the image
-__global__ void k_b2a(ImgGeom g, const uint8_t *occ, const double2 *B, double2 *A)
+__global__ void __launch_bounds__(TP * TRANSPOSE_ROWS) k_b2a(ImgGeom g, const uint8_t *occ, const double2 *B, double2 *A)
 {
     __shared__ double2 t[TP][TP + 1];
     if (!occ[blockIdx.x]) return;
     const int u0 = blockIdx.x * TP, v0 = blockIdx.y * TP;
     const int hy = g.ny / 2;
-    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+#pragma unroll
+    for (int kk = 0; kk < TP / TRANSPOSE_ROWS; ++kk) {
+        const int k = int(threadIdx.y) + kk * TRANSPOSE_ROWS;
         int v = v0 + k, u = u0 + threadIdx.x;
         int y = -1;
         if (v < g.ny - hy) y = v + hy;
@@ -351,7 +359,9 @@ __global__ void k_b2a(ImgGeom g, const uint8_t *occ, const double2 *B, double2 *
         t[k][threadIdx.x] = val;
     }
     __syncthreads();
-    for (int k = threadIdx.y; k < TP; k += blockDim.y) {
+#pragma unroll
+    for (int kk = 0; kk < TP / TRANSPOSE_ROWS; ++kk) {
+        const int k = int(threadIdx.y) + kk * TRANSPOSE_ROWS;
         int u = u0 + k, v = v0 + threadIdx.x;
         if (u < g.nu && v < g.nv) A[size_t(u) * g.nv + v] = t[threadIdx.x][k];
     }
@@ -779,7 +789,7 @@ struct pfbhip_gridder {
                 const int p = p0 + k;
                 fft_rows_A(false, k);
                 timer.begin(4);
-                hipLaunchKernelGGL(k_a2b, tgrid(info.nu, prm.ny), dim3(TP, 8), 0, stream, geom, d_occ.p,
+                hipLaunchKernelGGL(k_a2b, tgrid(info.nu, prm.ny), dim3(TP, TRANSPOSE_ROWS), 0, stream, geom, d_occ.p,
                                    grid_cur + size_t(k) * plane_stride, d_gridB.p + (fused ? size_t(k) * bstride : 0),
                                    fused ? 0 : 1);
                 PFB_HIP(hipGetLastError());
@@ -892,7 +902,7 @@ struct pfbhip_gridder {
                     fft_rows_B(true);
                 }
                 timer.begin(3);
-                hipLaunchKernelGGL(k_b2a, tgrid(info.nu, info.nv), dim3(TP, 8), 0, stream, geom, d_occ.p,
+                hipLaunchKernelGGL(k_b2a, tgrid(info.nu, info.nv), dim3(TP, TRANSPOSE_ROWS), 0, stream, geom, d_occ.p,
                                    d_gridB.p + (fused ? size_t(k) * bstride : 0), grid_cur + size_t(k) * plane_stride);
                 PFB_HIP(hipGetLastError());
                 timer.end();
