@@ -169,6 +169,10 @@ int pfbhip_gridder_grid_dev(pfbhip_gridder *g, const double *vis_sorted_dev, dou
 #define PFBHIP_NSTAGES 8
 int pfbhip_gridder_profile(pfbhip_gridder *g, int enable);
 int pfbhip_gridder_profile_get(pfbhip_gridder *g, double *ms /* [PFBHIP_NSTAGES] */, int64_t *calls, int reset);
+/* Diagnostic (plans created with PFBHIP_STAMP=1 in the environment): in-kernel phase stamps (shader cycles) of the last
+ * record-scatter pass, 8 words per colour work item: prologue, wave 0 visibility loop, wave 0 barrier wait, tile flush,
+ * visibilities, last wave's loop, last wave's wait, tile.  *nitems = 0 when stamping is off. */
+int pfbhip_gridder_debug_stamps(pfbhip_gridder *g, unsigned long long *out_host, int64_t capacity_items, int64_t *nitems);
 
 /* ---- FFT (replaces ducc0.fft.r2c / c2r) ---------------------------- */
 /* r2c(forward=True, inorm=0) and c2r(forward=False, inorm=2, lastsize) over the last two axes of a

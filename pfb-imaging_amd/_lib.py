@@ -68,6 +68,7 @@ SYMBOLS = (
     "pfbhip_gridder_vis2dirty", "pfbhip_gridder_dirty2vis", "pfbhip_gridder_grid_plane",
     "pfbhip_gridder_set_weights", "pfbhip_gridder_hessian", "pfbhip_gridder_hessian_dev",
     "pfbhip_gridder_degrid_dev", "pfbhip_gridder_grid_dev", "pfbhip_gridder_profile", "pfbhip_gridder_profile_get",
+    "pfbhip_gridder_debug_stamps",
     "pfbhip_gridder_cg",
     "pfbhip_r2c_2d", "pfbhip_c2r_2d", "pfbhip_debug_rowfft",
     "pfbhip_psi_create", "pfbhip_psi_destroy", "pfbhip_psi_shape", "pfbhip_psi_dot", "pfbhip_psi_hdot",

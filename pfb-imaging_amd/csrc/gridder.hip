@@ -518,6 +518,11 @@ struct pfbhip_gridder {
     DevBuf<double2> d_gridB;  // (ny, nu) transposed / cropped plane
     DevBuf<double> d_accT;    // (ny, nx) transposed image accumulator / transposed degrid input
     DevBuf<uint8_t> d_occ;    // occupancy of 32-row blocks of the uv-plane
+    // first-axis row FFTs with the crop / pad + transpose folded in (rowfft_a2b / rowfft_b2a): row of every workgroup,
+    // ordered so that the 8 rows of a 128-byte line of B run on one XCD at about the same time (PFBHIP_TFFT=0: the
+    // separate k_a2b / k_b2a passes; =2: rows in natural order)
+    DevBuf<int> d_rowmap;
+    int tfft = 0;
     bool weights_bound = false;
     struct RowSpan {
         int64_t row0, nrows;                      // occupied rows [row0, row0 + nrows) of A
@@ -558,7 +563,7 @@ struct pfbhip_gridder {
                d_cfu.bytes() + d_cfv.bytes() + d_cheb.bytes() + d_ktab.bytes() + d_mask.bytes() + d_src.bytes() + d_work.bytes() + d_work_col.bytes() +
                d_grid.bytes() + d_grid2.bytes() + d_sval.bytes() + d_sacc.bytes() + d_vis.bytes() + d_wgt.bytes() + d_swgt.bytes() +
                d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes() + d_gridB.bytes() +
-               d_accT.bytes() + d_occ.bytes();
+               d_accT.bytes() + d_occ.bytes() + d_rowmap.bytes() + d_rec.bytes() + d_pval.bytes() + d_kw.bytes();
     }
 
     PlaneArgs plane_args(int plane) const
@@ -620,6 +625,8 @@ struct pfbhip_gridder {
         for (int k = 0; k < KP_MAX; ++k)
             ga.coefk[k] = (info.wmode == 1 && k < kp) ? lagr_coef[size_t(plane0 + k)] : 1.0;
         ga.plane_stride = plane_stride;
+        ga.dbg = nullptr;
+        for (int q = 0; q < 3; ++q) ga.wshare[q] = wshare[q];
         return ga;
     }
     // dynamic LDS: kp_max tiles (re/im or interleaved complex) + the (W, D+1) kernel table
@@ -667,6 +674,32 @@ struct pfbhip_gridder {
         hipLaunchKernelGGL((k_grid_blk<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, sval, grid_cur);
     }
     bool scatter_blk = true;  // register-footprint scatter (k_grid_blk); PFBHIP_SCATTER=walk selects k_grid_mp
+    // record-driven register-footprint scatter (k_grid_rec): single-pass plans without ES-kernel w-planes
+    // (PFBHIP_SCATTER=block keeps k_grid_blk).  d_rec: static per-visibility records; d_pval: the plane-weighted values
+    // of the current apply (kp_max per visibility), written by the gather inside a Hessian apply (pval_ready) or by
+    // k_plane_values in front of the scatter
+    bool scatter_rec = false, pval_ready = false, want_pval = false;
+    DevBuf<VisRec> d_rec;
+    // row-walk gather (k_degrid_rw): same plans as the record scatter; d_kw: plane weights of every visibility (plan time)
+    bool gather_rw = false;
+    DevBuf<double> d_kw;
+    float wshare[3] = {1.f / 3, 1.f / 3, 1.f / 3};  // see GroupArgs::wshare (PFBHIP_WSHARE=a,b,c overrides)
+    DevBuf<unsigned long long> d_stamps;  // PFBHIP_STAMP=1: in-kernel phase stamps of the record scatter (8 words per colour work item)
+    DevBuf<double2> d_pval;
+    template <int W, int KP>
+    void launch_grid_rec_wk(const GroupArgs &ga)
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_rec<W, KP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        const size_t lds = lds_bytes_blk<W, KP>();
+        PFB_REQUIRE(lds <= size_t(160) * 1024, "record scatter needs %zu bytes of LDS", lds);
+        hipLaunchKernelGGL((k_grid_rec<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, d_rec.p, d_pval.p,
+                           grid_cur);
+    }
     template <int W>
     void launch_grid_mp_w(int plane0, int kp, const double2 *sval)
     {
@@ -674,11 +707,28 @@ struct pfbhip_gridder {
         if (ga.a.nwork == 0) return;
         if (scatter_blk) {
             const size_t grp = work_off.size() > 1 ? size_t(plane0 / kp_max) : 0;
-            for (int col = 0; col < 4; ++col) {  // one launch per tile colour (see k_grid_blk's flush)
+            if (scatter_rec && !pval_ready) {
+                timer.begin(5);
+                hipLaunchKernelGGL((k_plane_values<W>), dim3(uint32_t(ceil_div(info.nactive, 256))), dim3(256), 0, stream, ga,
+                                   info.nactive, sval, d_pval.p);
+                timer.end();
+            }
+            for (int col = 0; col < 4; ++col) {  // one launch per tile colour (see blk_tile_to_grid)
                 ga.a.work = d_work_col.p + col_off[grp * 4 + size_t(col)];
                 ga.a.nwork = uint32_t(col_cnt[grp * 4 + size_t(col)]);
                 if (ga.a.nwork == 0) continue;
                 timer.begin(0);
+                if (scatter_rec) {
+                    if (d_stamps.p != nullptr) ga.dbg = d_stamps.p + (col_off[grp * 4 + size_t(col)]) * 8;
+                    switch (kp) {
+                        case 1: launch_grid_rec_wk<W, 1>(ga); break;
+                        case 2: launch_grid_rec_wk<W, 2>(ga); break;
+                        case 3: launch_grid_rec_wk<W, 3>(ga); break;
+                        default: launch_grid_rec_wk<W, 4>(ga); break;
+                    }
+                    timer.end();
+                    continue;
+                }
                 switch (kp) {
                     case 1: launch_grid_blk_wk<W, 1>(ga, sval); break;
                     case 2: launch_grid_blk_wk<W, 2>(ga, sval); break;
@@ -708,13 +758,35 @@ struct pfbhip_gridder {
             attr_set = true;
         }
         hipLaunchKernelGGL((k_degrid_mp<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga,
-                           grid_cur, sacc);
+                           grid_cur, sacc, want_pval ? d_swgt.p : nullptr, want_pval ? d_pval.p : nullptr);
+    }
+    template <int W, int KP>
+    void launch_degrid_rw_wk(const GroupArgs &ga, double2 *sacc)
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_degrid_rw<W, KP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        const size_t lds = size_t(KP) * RW_LS * RW_LS * sizeof(double2);
+        hipLaunchKernelGGL((k_degrid_rw<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds, stream, ga, d_rec.p, d_kw.p, grid_cur,
+                           sacc, want_pval ? d_swgt.p : nullptr, want_pval ? d_pval.p : nullptr);
     }
     template <int W>
     void launch_degrid_mp_w(int plane0, int kp, double2 *sacc)
     {
         GroupArgs ga = group_args(plane0, kp);
         if (ga.a.nwork == 0) return;
+        if (gather_rw) {
+            switch (kp) {
+                case 1: launch_degrid_rw_wk<W, 1>(ga, sacc); break;
+                case 2: launch_degrid_rw_wk<W, 2>(ga, sacc); break;
+                case 3: launch_degrid_rw_wk<W, 3>(ga, sacc); break;
+                default: launch_degrid_rw_wk<W, 4>(ga, sacc); break;
+            }
+            return;
+        }
         switch (kp) {
             case 1: launch_degrid_mp_wk<W, 1>(ga, sacc); break;
             case 2: launch_degrid_mp_wk<W, 2>(ga, sacc); break;
@@ -787,6 +859,13 @@ struct pfbhip_gridder {
             PFB_HIP(hipGetLastError());
             for (int k = 0; k < kp; ++k) {
                 const int p = p0 + k;
+                if (tfft) {
+                    timer.begin(2);
+                    rowfft_a2b(rowfft_v.pl, grid_cur + size_t(k) * plane_stride, d_gridB.p + size_t(k) * bstride, d_rowmap.p,
+                               int(occ_rows), int(info.nu), int(prm.ny), stream);
+                    timer.end();
+                    continue;
+                }
                 fft_rows_A(false, k);
                 timer.begin(4);
                 hipLaunchKernelGGL(k_a2b, tgrid(info.nu, prm.ny), dim3(TP, TRANSPOSE_ROWS), 0, stream, geom, d_occ.p,
@@ -880,7 +959,7 @@ struct pfbhip_gridder {
     // `prep` (fused path only): the fused pad kernel reads x * corr [* beam] itself instead of a prepared accT
     void degrid_all_planes(double2 *sacc, const FusedPrep *prep = nullptr)
     {
-        PFB_HIP(hipMemsetAsync(sacc, 0, size_t(std::max<int64_t>(info.nactive, 1)) * sizeof(double2), stream));
+        if (!want_pval) PFB_HIP(hipMemsetAsync(sacc, 0, size_t(std::max<int64_t>(info.nactive, 1)) * sizeof(double2), stream));
         if (info.nactive == 0 || info.nwork == 0) return;
         for (int p0 = 0; p0 < info.nplanes; p0 += kp_max) {
             const int kp = int(std::min<int64_t>(kp_max, info.nplanes - p0));
@@ -900,6 +979,13 @@ struct pfbhip_gridder {
                     PFB_HIP(hipGetLastError());
                     timer.end();
                     fft_rows_B(true);
+                }
+                if (tfft) {
+                    timer.begin(2);
+                    rowfft_b2a(rowfft_v.pl, d_gridB.p + size_t(k) * bstride, grid_cur + size_t(k) * plane_stride, d_rowmap.p,
+                               int(occ_rows), int(info.nu), int(prm.ny), stream);
+                    timer.end();
+                    continue;
                 }
                 timer.begin(3);
                 hipLaunchKernelGGL(k_b2a, tgrid(info.nu, info.nv), dim3(TP, TRANSPOSE_ROWS), 0, stream, geom, d_occ.p,
@@ -1293,7 +1379,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     {
         size_t per_pass = work.size();
         for (size_t c : g->work_cnt) per_pass = std::min(per_pass, c);
-        if (g->scatter_blk && smode != "block" && per_pass < size_t(2048)) g->scatter_blk = false;
+        if (g->scatter_blk && smode != "block" && smode != "rec" && per_pass < size_t(2048)) g->scatter_blk = false;
     }
     {
         // colour slices of every group's list (LPT order kept inside a slice); chunks of a tile that has several in the
@@ -1330,6 +1416,62 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         if (!wcol.empty())
             PFB_HIP(hipMemcpyAsync(g->d_work_col.p, wcol.data(), wcol.size() * sizeof(WorkItem), hipMemcpyHostToDevice, st));
         PFB_HIP(hipStreamSynchronize(st));  // wcol is a local
+    }
+    const bool rec_mode = info.nplanes <= g->kp_max && (!prm.do_wgridding || info.wmode == 1) && info.nactive > 0 && !work.empty();
+    g->scatter_rec = rec_mode && g->scatter_blk && smode != "block";
+    {
+        const char *genv = std::getenv("PFBHIP_GATHER");
+        g->gather_rw = rec_mode && !(genv != nullptr && std::string(genv) == "walk");
+    }
+    if (rec_mode) {
+        g->d_rec.alloc(size_t(info.nactive) + REC_PAD);
+        g->d_pval.alloc((size_t(info.nactive) + REC_PAD) * size_t(g->kp_max));
+        PFB_HIP(hipMemsetAsync(g->d_pval.p, 0, g->d_pval.bytes(), st));
+        switch (info.W) {
+#define PFB_CASE(w)                                                                                                      \
+    case w:                                                                                                              \
+        hipLaunchKernelGGL((k_vis_records<w>), blocks1d(info.nactive + REC_PAD), dim3(256), 0, st, int(info.nu), int(info.nv), \
+                           info.nactive, g->d_pu.p, g->d_pv.p, g->d_rec.p);                                              \
+        break;
+            PFB_CASE(4) PFB_CASE(5) PFB_CASE(6) PFB_CASE(7) PFB_CASE(8) PFB_CASE(9) PFB_CASE(10) PFB_CASE(11)
+            PFB_CASE(12) PFB_CASE(13) PFB_CASE(14) PFB_CASE(15) PFB_CASE(16)
+#undef PFB_CASE
+            default: throw std::runtime_error("unsupported kernel support");
+        }
+        PFB_HIP(hipGetLastError());
+        if (g->gather_rw) {
+            g->d_kw.alloc((size_t(info.nactive) + REC_PAD) * size_t(g->kp_max));
+            // (the planes / polynomial nodes are set by choose_kernel; the work list is not needed here)
+            GroupArgs ga = g->group_args(0, int(info.nplanes));
+            switch (info.W) {
+#define PFB_CASE(w)                                                                                                   \
+    case w:                                                                                                           \
+        hipLaunchKernelGGL((k_plane_weights<w>), blocks1d(info.nactive + REC_PAD), dim3(256), 0, st, ga, info.nactive, \
+                           g->d_kw.p);                                                                                \
+        break;
+                PFB_CASE(4) PFB_CASE(5) PFB_CASE(6) PFB_CASE(7) PFB_CASE(8) PFB_CASE(9) PFB_CASE(10) PFB_CASE(11)
+                PFB_CASE(12) PFB_CASE(13) PFB_CASE(14) PFB_CASE(15) PFB_CASE(16)
+#undef PFB_CASE
+                default: throw std::runtime_error("unsupported kernel support");
+            }
+            PFB_HIP(hipGetLastError());
+        }
+        PFB_HIP(hipStreamSynchronize(st));
+        if (const char *wenv = std::getenv("PFBHIP_WSHARE")) {
+            float a = 1, b = 1, c = 1;
+            if (sscanf(wenv, "%f,%f,%f", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) {
+                g->wshare[0] = a / (a + b + c);
+                g->wshare[1] = b / (a + b + c);
+                g->wshare[2] = c / (a + b + c);
+            }
+        }
+        const char *stenv = std::getenv("PFBHIP_STAMP");
+        if (stenv != nullptr && stenv[0] == '1') {
+            size_t nitems = 0;
+            for (size_t c : g->col_cnt) nitems += c;
+            g->d_stamps.alloc(std::max<size_t>(nitems, 1) * 8);
+            PFB_HIP(hipMemset(g->d_stamps.p, 0, g->d_stamps.bytes()));
+        }
     }
     info.scatter_launches = (g->scatter_blk && g->coloured) ? 4 : 1;
     info.nwork = int64_t(work.size());
@@ -1428,7 +1570,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     }
     info.fft_mode = (g->rowfft_v.ok ? 1 : 0) | (g->fused ? 2 : 0) | ((!g->fused && g->rowfft_u.ok) ? 4 : 0);
     info.screen_poly = g->fgeom.npoly;
-    info.scatter_mode = g->scatter_blk ? 1 : 0;
+    info.scatter_mode = g->scatter_rec ? 2 : (g->scatter_blk ? 1 : 0);
     g->bstride = size_t(prm.ny) * size_t(info.nu);
     g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
     g->d_accT.alloc(size_t(npix));
@@ -1493,6 +1635,31 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         g->fftB_bwd = make_rows(info.nu, prm.ny, false);
     }
     info.occ_rows = int32_t(g->occ_rows);
+    {
+        const char *tenv = std::getenv("PFBHIP_TFFT");
+        const int want = tenv != nullptr ? std::atoi(tenv) : 1;
+        g->tfft = (want != 0 && g->fused && g->rowfft_v.ok && !g->rowfft_v.pl.doubled && g->occ_rows > 0) ? want : 0;
+        if (g->tfft) {
+            std::vector<int> rows;
+            rows.reserve(size_t(g->occ_rows));
+            for (auto &sp : g->spans)
+                for (int64_t r = 0; r < sp.nrows; ++r) rows.push_back(int(sp.row0 + r));
+            const size_t n = rows.size(), ngroups = n / 8, nfull = ngroups / 8;
+            std::vector<int> map(n);
+            for (size_t b = 0; b < n; ++b) {
+                if (g->tfft == 1 && b < nfull * 64) {  // super-group of 64 block ids = 8 XCDs x 8 adjacent rows
+                    const size_t sg = b / 64, r = b % 64, xcd = r % 8, k = r / 8;
+                    map[b] = rows[(sg * 8 + xcd) * 8 + k];
+                } else {
+                    map[b] = rows[b];
+                }
+            }
+            g->d_rowmap.alloc(n);
+            PFB_HIP(hipMemcpyAsync(g->d_rowmap.p, map.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+            PFB_HIP(hipStreamSynchronize(st));
+        }
+        info.fft_mode |= g->tfft ? 8 : 0;
+    }
     if (any_rocfft) {
         PFB_ROCFFT(rocfft_execution_info_create(&g->fft_info));
         if (wmax) {
@@ -1690,14 +1857,25 @@ static void hessian_dev_impl(pfbhip_gridder *g, const double *x_dev, const doubl
     // clear's HBM traffic is free there; next to the row-FFT stages it only takes their bandwidth): see side_clear()
     g->side_clear_pending = side;
     g->side_clear_done = false;
+    // record scatter: the gather's epilogue writes the weighted, plane-weighted model visibilities (no sacc, no scaling pass)
+    g->want_pval = g->scatter_rec && g->info.nwork > 0;
+    struct ClearFlags {
+        pfbhip_gridder *g;
+        ~ClearFlags() { g->want_pval = g->pval_ready = false; }
+    } clear_flags{g};
     g->prepare_and_degrid(x_dev, beam_dev, g->d_sacc.p);
     g->side_clear_pending = false;
-    g->timer.begin(5);
-    if (g->info.nactive)
-        hipLaunchKernelGGL(k_scale_sorted, blocks1d(g->info.nactive), dim3(256), 0, st, g->info.nactive, g->d_sacc.p,
-                           g->d_swgt.p, g->d_sval.p);
-    PFB_HIP(hipGetLastError());
-    g->timer.end();
+    if (g->want_pval) {
+        g->want_pval = false;
+        g->pval_ready = true;
+    } else {
+        g->timer.begin(5);
+        if (g->info.nactive)
+            hipLaunchKernelGGL(k_scale_sorted, blocks1d(g->info.nactive), dim3(256), 0, st, g->info.nactive, g->d_sacc.p,
+                               g->d_swgt.p, g->d_sval.p);
+        PFB_HIP(hipGetLastError());
+        g->timer.end();
+    }
     if (g->side_clear_done) {
         PFB_HIP(hipStreamWaitEvent(st, g->ev_clear, 0));
         g->grid_cur = g->d_grid2.p;
@@ -1811,6 +1989,22 @@ int pfbhip_gridder_grid_dev(pfbhip_gridder *g, const double *vis_sorted_dev, dou
         PFB_REQUIRE(g && dirty_dev && vis_sorted_dev, "NULL argument");
         g->grid_and_finalize(reinterpret_cast<const double2 *>(vis_sorted_dev), nullptr, 1.0, 0.0, nullptr, dirty_dev);
         PFB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+
+// Diagnostic (PFBHIP_STAMP=1 at plan creation): the in-kernel phase stamps of the last record-scatter pass, 8 words per
+// colour work item; returns the number of items through *nitems (0: stamping is off).
+int pfbhip_gridder_debug_stamps(pfbhip_gridder *g, unsigned long long *out_host, int64_t capacity_items, int64_t *nitems)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && nitems, "NULL argument");
+        const int64_t n = g->d_stamps.p ? int64_t(g->d_stamps.n / 8) : 0;
+        *nitems = n;
+        if (n && out_host) {
+            PFB_HIP(hipStreamSynchronize(g->stream));
+            PFB_HIP(hipMemcpy(out_host, g->d_stamps.p, size_t(std::min(n, capacity_items)) * 8 * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost));
+        }
     });
 }
 

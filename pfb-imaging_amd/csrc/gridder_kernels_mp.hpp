@@ -24,6 +24,8 @@
 // its row's visibility (Lagrange basis polynomial at the visibility's abscissa, or the W-wide ES
 // kernel in w); the KP values are then broadcast inside the row.
 #pragma once
+#include <type_traits>
+
 #include "gridder_kernels.hpp"
 
 namespace pfbhip {
@@ -37,6 +39,11 @@ struct GroupArgs {
     int kp_alloc;            // planes the LDS allocation holds (the plan's planes per pass)
     double coefk[KP_MAX];    // wmode 1: Lagrange denominators of the group's planes
     size_t plane_stride;     // complex elements between consecutive planes of the uv-grid buffer
+    // k_grid_rec: relative share of a work item's visibilities given to the waves of age class 0 (the first NW/3 waves, the
+    // oldest on their SIMDs), 1 and 2.  The SIMD arbitrates VALU issue by age, so equal shares finish 37K / 50K / 62K
+    // cycles apart (stamps, C2) and the barrier waits for the youngest.
+    float wshare[3];
+    unsigned long long *dbg; // diagnostic build / PFBHIP_STAMP=1 only: 8 words per work item of in-kernel phase stamps (else NULL)
 };
 
 // weight of plane `plane` for abscissa/coordinate pw
@@ -198,13 +205,85 @@ __host__ __device__ constexpr int blk_rows_per_lane(int W) { return (W + BLK_CEL
 // stride of +-11 doubles mod 32 spreads them over the 64 banks two-deep (the minimum for 60 doubles); an even stride
 // puts two of the three rows on the same banks.  The wide stride is used when the tiles of KP planes still fit.
 __host__ __device__ constexpr int blk_tile_rows(int W) { return TILE + W - 1; }
-__host__ __device__ constexpr size_t blk_fixed_doubles(int W, int waves) { return size_t(W) * (kernel_poly_degree_c(W) + 1) + size_t(waves) * 2 * BLK_SCRATCH; }
+__host__ __device__ constexpr size_t blk_fixed_doubles(int W, int waves) { return size_t(W) * (kernel_poly_degree_c(W) + 1) + size_t(waves) * 3 * BLK_SCRATCH; }  // (k_grid_rec uses three scratch lines per wave, k_grid_blk two)
 __host__ __device__ constexpr int blk_stride(int W, int KP)
 {
     const int L = TILE + W - 1;
     const int wide = L <= 43 ? 43 : 53;
     const size_t bytes = (size_t(2) * KP * L * wide + blk_fixed_doubles(W, 12)) * sizeof(double);
     return bytes <= size_t(160) * 1024 ? wide : ((L & 1) ? L + 1 : L);
+}
+
+// Tile -> uv-grid of the register-footprint scatters (k_grid_blk, k_grid_rec); every thread of the workgroup calls it
+// after the barrier that ends the visibility loop.
+template <int W, int KP>
+__device__ __forceinline__ void blk_tile_to_grid(const GroupArgs &ga, const WorkItem &wi, const double *lds, int bu, int bv,
+                                                 double2 *__restrict__ grid)
+{
+    const PlaneArgs &a = ga.a;
+    constexpr int L = TILE + W - 1;
+    constexpr int LS = blk_stride(W, KP);
+    constexpr int LL = blk_tile_rows(W) * LS;
+    const int BLK_THREADS = int(blockDim.x);
+    // Tile -> uv-grid.  The (TILE + W - 1)^2 regions of tiles two apart in each direction are disjoint (W - 1 < TILE), so
+    // within one launch of a single COLOUR (tile-row parity, tile-column parity) nobody else touches this region: a plain
+    // coalesced read-add-write of whole complex cells.  Device-scope f64 atomics execute at the memory side, one 8-byte
+    // operation per transaction: flushing every tile of C2 that way takes 2.7 ms per launch, the plain form 0.5 ms.
+    // Work items flagged `shared` (several chunks of one tile in the same launch, or a plan without colours) keep the atomics.
+    const bool shared = wi.pad != 0;
+    if (shared) {
+        for (int k = 0; k < KP; ++k) {
+            double *gp = reinterpret_cast<double *>(grid + size_t(k) * ga.plane_stride);
+            const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
+            for (int i = threadIdx.x; i < L * L; i += BLK_THREADS) {
+                const int la = i / L, lb = i - la * L;
+                const double re = lre[la * LS + lb], im = lim[la * LS + lb];
+                if (re != 0.0 || im != 0.0) {
+                    int gu = bu + la, gv = bv + lb;
+                    gu = gu >= a.nu ? gu % a.nu : gu;
+                    gv = gv >= a.nv ? gv % a.nv : gv;
+                    const size_t o = (size_t(gu) * size_t(a.nv) + size_t(gv)) * 2;
+                    unsafeAtomicAdd(&gp[o], re);
+                    unsafeAtomicAdd(&gp[o + 1], im);
+                }
+            }
+        }
+        return;
+    }
+    // all loads of the thread's cells first (a load -> add -> store chain per cell would expose the HBM latency once per
+    // cell: ~9 cells per thread), then the stores
+    constexpr int NJ = (L * L + 511) / 512;  // cells per thread and plane at the smallest workgroup
+    size_t off[NJ];
+    int lo[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = int(threadIdx.x) + j * BLK_THREADS;
+        const int la = i / L, lb = i - la * L;
+        int gu = bu + la, gv = bv + lb;
+        gu = gu >= a.nu ? gu % a.nu : gu;
+        gv = gv >= a.nv ? gv % a.nv : gv;
+        off[j] = size_t(gu) * size_t(a.nv) + size_t(gv);
+        lo[j] = i < L * L ? la * LS + lb : -1;
+    }
+    double2 v[KP][NJ];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const double2 *gk = grid + size_t(k) * ga.plane_stride;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (lo[j] >= 0) v[k][j] = gk[off[j]];
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        double2 *gk = grid + size_t(k) * ga.plane_stride;
+        const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (lo[j] >= 0) {
+                const double re = lre[lo[j]], im = lim[lo[j]];
+                if (re != 0.0 || im != 0.0) gk[off[j]] = make_double2(v[k][j].x + re, v[k][j].y + im);
+            }
+    }
 }
 
 template <int W, int KP>
@@ -363,70 +442,534 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
     }
     if (cur >= 0) flush(cur);
     __syncthreads();
-    // Tile -> uv-grid.  The (TILE + W - 1)^2 regions of tiles two apart in each direction are disjoint (W - 1 < TILE), so
-    // within one launch of a single COLOUR (tile-row parity, tile-column parity) nobody else touches this region: a plain
-    // coalesced read-add-write of whole complex cells.  Device-scope f64 atomics execute at the memory side, one 8-byte
-    // operation per transaction: flushing every tile of C2 that way takes 2.7 ms per launch, the plain form 0.5 ms.
-    // Work items flagged `shared` (several chunks of one tile in the same launch, or a plan without colours) keep the atomics.
-    const bool shared = wi.pad != 0;
-    if (shared) {
-        for (int k = 0; k < KP; ++k) {
-            double *gp = reinterpret_cast<double *>(grid + size_t(k) * ga.plane_stride);
-            const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
-            for (int i = threadIdx.x; i < L * L; i += BLK_THREADS) {
-                const int la = i / L, lb = i - la * L;
-                const double re = lre[la * LS + lb], im = lim[la * LS + lb];
-                if (re != 0.0 || im != 0.0) {
-                    int gu = bu + la, gv = bv + lb;
-                    gu = gu >= a.nu ? gu % a.nu : gu;
-                    gv = gv >= a.nv ? gv % a.nv : gv;
-                    const size_t o = (size_t(gu) * size_t(a.nv) + size_t(gv)) * 2;
-                    unsafeAtomicAdd(&gp[o], re);
-                    unsafeAtomicAdd(&gp[o + 1], im);
+    blk_tile_to_grid<W, KP>(ga, wi, lds, bu, bv, grid);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Scatter, register-footprint form driven by per-visibility RECORDS (k_grid_rec): single-pass plans with polynomial
+// w-planes (every visibility touches every plane of the one pass).
+//
+// What the in-kernel stamps of k_grid_blk / the first k_grid_rec showed (tools/stamp_scatter.py, C2): a wave issues at
+// most ONE instruction -- vector, scalar, LDS, branch or wait -- per 4 cycles, so a visibility costs a wave 4 x (all its
+// instructions), not 4 x (its FMAs); the three waves of a SIMD overlap, but the SIMD arbitrates by age, so with equal
+// shares the oldest wave of a SIMD finishes at 60 % of the youngest wave's time and the barrier waits for the youngest.
+// Hence:
+//  * everything that does not depend on the visibility VALUES is computed once per plan (k_vis_records) in the form
+//    the loop consumes: kernel arguments (zu, zv), the 4 x 4-cell block id, and the two scratch-read byte offsets;
+//  * the values arrive already multiplied by the plane weights (KP complex numbers per visibility: written by the
+//    gather's epilogue in a Hessian apply, by k_plane_values otherwise);
+//  * key / offsets / values are wave-uniform and come in through SCALAR loads (SGPR operands of the FMAs: no
+//    v_readlane), the kernel argument through one vector load (lanes 0..15 read zu, lanes 16..31 zv); records are
+//    addressed with running 32-bit byte offsets (arrays padded by REC_PAD entries: no clamping);
+//  * three register sets and three scratch lines used round robin by a loop unrolled three times (static indices):
+//    a visibility's data are requested two iterations before use;
+//  * the scalar requests are issued BEHIND the wait for the scratch reads (scalar loads return out of order: a wait on
+//    LDS data while one is pending waits for it too);
+//  * age classes of waves get unequal shares (GroupArgs::wshare).
+struct VisRec {
+    double zu, zv;  // 2 frac - 1 of the first-tap offset on the plan's u and v axis
+    int blk;        // ((lu >> 2) << 8) | (lv >> 2): 4 x 4-cell block of the first-tap cell inside the tile
+    int offu;       // 8 (G - (lu & 3)): byte offset of the u-kernel line reads
+    int offv;       // 8 (24 + G - (lv & 3)): byte offset of the v-kernel read
+    int key;        // (lu << 8) | lv: the first-tap cell itself (gather; SKIP test of k_grid_rec)
+};
+static_assert(sizeof(VisRec) == 32, "VisRec layout");
+constexpr int REC_PAD = 8;  // entries allocated past the last record / value (the loop requests up to 3 ahead)
+
+template <int W, int KP>
+__global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, const VisRec *__restrict__ rec,
+                                                               const double2 *__restrict__ pval, double2 *__restrict__ grid)
+{
+    const PlaneArgs &a = ga.a;
+    constexpr int D = kernel_poly_degree_c(W);
+    constexpr int LS = blk_stride(W, KP);
+    constexpr int LL = blk_tile_rows(W) * LS;
+    constexpr int FP = W + BLK_CELLS - 1;
+    constexpr int NR = blk_rows_per_lane(W);
+    constexpr int G = BLK_CELLS - 1;
+    constexpr bool SKIP = (FP % 3) == 1;
+    constexpr int NLINE = 3;  // scratch lines per wave (blk_fixed_doubles reserves 3 * BLK_SCRATCH per wave for this kernel)
+    const int BLK_THREADS = int(blockDim.x);
+    extern __shared__ double lds[];
+    double *wtab = lds + 2 * KP * LL;
+    double *scr_all = wtab + W * (D + 1);
+
+    const uint32_t item = blockIdx.x;
+    if (item >= a.nwork) return;
+    const bool stamp = ga.dbg != nullptr;
+    const unsigned long long ts0 = stamp ? __builtin_readcyclecounter() : 0ull;
+    const WorkItem wi = a.work[item];
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const uint32_t n = wi.end - wi.begin;
+    const uint32_t NW = uint32_t(BLK_THREADS) / 64;
+    // share boundaries: waves of one age class get equal shares, the classes ga.wshare[] of the total
+    auto share_begin = [&](uint32_t w) {
+        const uint32_t per = NW / 3, cls = min(w / max(per, 1u), 2u), in = w - cls * per;
+        float f = 0.f;
+        for (uint32_t q = 0; q < cls; ++q) f += ga.wshare[q];
+        const uint32_t ncls = cls == 2 ? NW - 2 * per : per;
+        f += ga.wshare[cls] * float(in) / float(max(ncls, 1u));
+        return w >= NW ? n : min(uint32_t(f * float(n)), n);
+    };
+    const uint32_t j0 = wi.begin + share_begin(uint32_t(wave));
+    const uint32_t j1 = wi.begin + share_begin(uint32_t(wave) + 1);
+    const uint32_t nmine = j1 - j0;
+    const uint32_t pbytes = uint32_t(ga.kp_alloc) * 16u;  // bytes of values per visibility
+    const char *rbase = reinterpret_cast<const char *>(rec);
+    const char *pbase = reinterpret_cast<const char *>(pval);
+    // per-lane kernel-argument pointer (zu for lanes 0..15, zv for 16..31), coefficients requested before the tile is cleared
+    const char *zptr = rbase + size_t(j0) * 32 + (lane < 16 ? 0 : 8);
+    const int b = lane & 15;
+    double c[D + 1];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) c[k] = (b < W && lane < 32) ? a.ktab[b * (D + 1) + k] : 0.0;
+    // Warm the L2 with the records / values of 64 visibilities (one per lane) ahead of the walk, whose own requests --
+    // two visibilities ahead -- then never wait for HBM.  The loaded words are consumed (an empty asm) at the next refresh.
+    auto touch = [&](uint32_t first) {
+        const uint32_t jt = first + uint32_t(lane);  // (padded arrays: no clamp)
+        const int t0 = *reinterpret_cast<const int *>(rbase + size_t(jt) * 32 + 16);
+        const double t1 = *reinterpret_cast<const double *>(pbase + size_t(jt) * pbytes);
+        return double(t0) + t1;
+    };
+    double warm = touch(j0);
+    double zq[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) zq[u] = *reinterpret_cast<const double *>(zptr + u * 32);
+
+    for (int i = threadIdx.x; i < 2 * KP * LL; i += BLK_THREADS) lds[i] = 0.0;
+    for (int i = threadIdx.x; i < W * (D + 1); i += BLK_THREADS) wtab[i] = a.ktab[i];
+    for (int i = threadIdx.x; i < (BLK_THREADS / 64) * NLINE * BLK_SCRATCH; i += BLK_THREADS) scr_all[i] = 0.0;
+
+    char *scr = reinterpret_cast<char *>(scr_all + wave * NLINE * BLK_SCRATCH);
+    const int g = lane / 20, cc = lane - 20 * g;
+    const bool act = g < 3 && cc < FP;
+    const int wslot = lane < 16 ? lane + G : (lane < 32 ? lane + 8 + G : lane + 16);
+    char *wptr = scr + wslot * 8;      // + line * BLK_SCRATCH * 8: where this lane writes its kernel value
+    const char *suptr = scr + g * 8;   // + offu + 24 k: u-kernel values of the lane's rows
+    const char *svptr = scr + cc * 8;  // + offv: v-kernel value of the lane's column
+    __syncthreads();
+
+    const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
+    const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
+
+    double are[NR][KP], aim[NR][KP];
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+        for (int p = 0; p < KP; ++p) are[k][p] = aim[k][p] = 0.0;
+
+    // footprint -> LDS tile: one address per flush (plane / row offsets are immediates where they fit 16 bits)
+    char *const tile0 = reinterpret_cast<char *>(lds) + (g * LS + cc) * 8;
+    auto flush = [&](int blk) {
+        const int r0 = (blk >> 8) * BLK_CELLS, c0 = (blk & 255) * BLK_CELLS;
+        char *base = tile0 + (r0 * LS + c0) * 8;
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                if (3 * k + g < FP) {
+#pragma unroll
+                    for (int p = 0; p < KP; ++p) {
+                        unsafeAtomicAdd(reinterpret_cast<double *>(base + ((2 * p) * LL + 3 * k * LS) * 8), are[k][p]);
+                        unsafeAtomicAdd(reinterpret_cast<double *>(base + ((2 * p + 1) * LL + 3 * k * LS) * 8), aim[k][p]);
+                    }
                 }
             }
         }
-        return;
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+#pragma unroll
+            for (int p = 0; p < KP; ++p) are[k][p] = aim[k][p] = 0.0;
+    };
+
+    // kernel values of one visibility: Horner in two independent half chains (even / odd powers), which a single wave can
+    // issue back to back (a 12-deep dependent f64 chain leaves it idle most of the time)
+    auto kernel_value = [&](double z) {
+        const double z2 = z * z;
+        double e = c[D], o = c[D - 1];
+#pragma unroll
+        for (int k = D - 2; k >= 0; k -= 2) {
+            e = fma(e, z2, c[k]);
+            if (k >= 1) o = fma(o, z2, c[k - 1]);
+        }
+        return (D & 1) ? fma(o, z, e) : fma(o, z, e);
+    };
+    static_assert((D & 1) == 0, "kernel_value assumes an even polynomial degree");
+    const unsigned long long ts1 = stamp ? __builtin_readcyclecounter() : 0ull;
+    if (nmine > 0) *reinterpret_cast<double *>(wptr) = kernel_value(zq[0]);  // stage A(0) -> line 0
+    int cur = -1;
+    int4 kq[3];
+    double2 pq[3][KP];
+    uint32_t roff = j0 * 32u + 16u, poff = j0 * pbytes;  // byte offsets of the next scalar requests (visibility s + 2 ...)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        kq[u] = *reinterpret_cast<const int4 *>(rbase + roff);
+#pragma unroll
+        for (int p = 0; p < KP; ++p) pq[u][p] = *reinterpret_cast<const double2 *>(pbase + poff + p * 16);
+        roff += 32u;
+        poff += pbytes;
     }
-    // all loads of the thread's cells first (a load -> add -> store chain per cell would expose the HBM latency once per
-    // cell: ~9 cells per thread), then the stores
-    constexpr int NJ = (L * L + 511) / 512;  // cells per thread and plane at the smallest workgroup
-    size_t off[NJ];
-    int lo[NJ];
+    kq[2] = make_int4(0, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int i = int(threadIdx.x) + j * BLK_THREADS;
-        const int la = i / L, lb = i - la * L;
-        int gu = bu + la, gv = bv + lb;
-        gu = gu >= a.nu ? gu % a.nu : gu;
-        gv = gv >= a.nv ? gv % a.nv : gv;
-        off[j] = size_t(gu) * size_t(a.nv) + size_t(gv);
-        lo[j] = i < L * L ? la * LS + lb : -1;
+    for (int p = 0; p < KP; ++p) pq[2][p] = make_double2(0.0, 0.0);
+    // consume the first scalars here: with scalar loads still pending at the loop header the compiler waits for
+    // lgkmcnt(0) at the top of EVERY iteration, right behind the loads it has just issued
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        asm volatile("" ::"s"(kq[u].x), "s"(kq[u].y), "s"(kq[u].z));
+#pragma unroll
+        for (int p = 0; p < KP; ++p) asm volatile("" ::"s"(pq[u][p].x), "s"(pq[u][p].y));
     }
-    double2 v[KP][NJ];
+    zptr += 3 * 32;  // next kernel argument to request: visibility s + 3
+    if (nmine > 0) cur = kq[0].x;
+    for (uint32_t wb = 0; wb < nmine; wb += 63) {  // L2 window: 63 visibilities = 21 trips of the unrolled loop
+        asm volatile("" ::"v"(warm));
+        warm = touch(j0 + wb + 63);
+        const uint32_t wend = min(wb + 63u, nmine);
+    for (uint32_t sb = wb; sb < wend; sb += 3) {
 #pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        const double2 *gk = grid + size_t(k) * ga.plane_stride;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            if (lo[j] >= 0) v[k][j] = gk[off[j]];
-    }
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        double2 *gk = grid + size_t(k) * ga.plane_stride;
-        const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            if (lo[j] >= 0) {
-                const double re = lre[lo[j]], im = lim[lo[j]];
-                if (re != 0.0 || im != 0.0) gk[off[j]] = make_double2(v[k][j].x + re, v[k][j].y + im);
+        for (int u = 0; u < 3; ++u) {
+            if (sb + uint32_t(u) >= wend) break;
+            const int ld = (u + 2) % 3, nx = (u + 1) % 3;
+            const double znext = zq[nx];                        // z(s + 1)
+            zq[u] = *reinterpret_cast<const double *>(zptr);  // z(s + 3); z(s) was consumed one iteration ago
+            zptr += 32;
+
+            const int4 rk = kq[u];
+            if (rk.x != cur) {
+                flush(cur);
+                cur = rk.x;
             }
+            const double kvc = *reinterpret_cast<const double *>(svptr + u * (BLK_SCRATCH * 8) + rk.z);
+            const char *su = suptr + u * (BLK_SCRATCH * 8) + rk.y;
+            double kuv[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) kuv[k] = *reinterpret_cast<const double *>(su + 24 * k);
+            *reinterpret_cast<double *>(wptr + nx * (BLK_SCRATCH * 8)) = kernel_value(znext);  // stage A(s + 1)
+            // The scalar requests for visibility s + 2 go out behind the wait for the scratch reads (the empty asm reads
+            // their destinations and is a compiler barrier for memory operations).  Issued here they have the FMAs below
+            // and the next iteration's kernel evaluation to arrive in.
+#pragma unroll
+            for (int k = 0; k < NR; ++k) asm volatile("" : "+v"(kuv[k])::"memory");
+            double kvc_ = kvc;
+            asm volatile("" : "+v"(kvc_)::"memory");
+            kq[ld] = *reinterpret_cast<const int4 *>(rbase + roff);
+#pragma unroll
+            for (int p = 0; p < KP; ++p) pq[ld][p] = *reinterpret_cast<const double2 *>(pbase + poff + p * 16);
+            roff += 32u;
+            poff += pbytes;
+            __builtin_amdgcn_sched_barrier(0);
+            // SKIP shapes (the block footprint has 3 m + 1 rows; W = 16: 19): row group 0 holds rows 0..2, the last group row
+            // 3 (NR - 1) only; a visibility whose origin sits in row du of its block touches rows du .. du + W - 1, i.e. group 0
+            // unless du == 3 and the last group only if du == 3 (du = bits 8..9 of rk.w, wave-uniform)
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                bool on = true;
+                if (SKIP && k == 0) on = (rk.w & 0x300) != 0x300;
+                if (SKIP && k == NR - 1) on = (rk.w & 0x300) == 0x300;
+                if (on) {
+                    const double t = kuv[k] * kvc_;
+#pragma unroll
+                    for (int p = 0; p < KP; ++p) {
+                        are[k][p] = fma(pq[u][p].x, t, are[k][p]);
+                        aim[k][p] = fma(pq[u][p].y, t, aim[k][p]);
+                    }
+                }
+            }
+            // "use" the record's spare fourth word when its set is current: otherwise its register is handed out again while
+            // the load that writes it is in flight, and that write waits for the load (an lgkmcnt(0) right behind the requests)
+            asm volatile("" ::"s"(rk.w));
+        }
+    }
+    }
+    asm volatile("" ::"v"(warm));
+    if (cur >= 0) flush(cur);
+    const unsigned long long ts2 = stamp ? __builtin_readcyclecounter() : 0ull;
+    __syncthreads();
+    const unsigned long long ts3 = stamp ? __builtin_readcyclecounter() : 0ull;
+    blk_tile_to_grid<W, KP>(ga, wi, lds, bu, bv, grid);
+    if (stamp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts4 = __builtin_readcyclecounter();
+        unsigned long long *d = ga.dbg + size_t(item) * 8;
+        if (threadIdx.x == 0) {
+            d[0] = ts1 - ts0;  // prologue (records requested, tile cleared, tables, barrier)
+            d[1] = ts2 - ts1;  // wave 0: its share of the visibilities
+            d[2] = ts3 - ts2;  // wave 0: wait for the slowest wave
+            d[3] = ts4 - ts3;  // tile -> uv-grid
+            d[4] = n;
+            d[7] = wi.tile;
+        }
+        if (threadIdx.x == uint32_t(BLK_THREADS) - 64) {
+            d[5] = ts2 - ts1;  // last wave's share
+            d[6] = ts3 - ts2;
+        }
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Gather, row walk with DPP-broadcast FMAs (k_degrid_rw): single-pass plans with polynomial w-planes.
+//
+// k_degrid_mp walks a footprint along diagonals so that the 16 lanes of a visibility hold 16 different u-kernel values:
+// per step 6 FMAs are accompanied by 3 DPP rotations and 2 address additions, and the per-visibility index arithmetic
+// and plane weights are recomputed every apply -- 79 VALU instructions per visibility, 30 % of them FMAs, and the
+// kernel is VALU-bound (a wave issues one instruction per 4 cycles whatever its kind).  gfx950 has a 64-bit DPP form of
+// v_fmac_f64 whose first operand is BROADCAST from a fixed lane of each 16-lane row (row_newbcast): with lane b on
+// footprint column cb and all 16 lanes on the same footprint row i, step i is
+//     acc += ku[lane i of my row] * cell(row i, my column)        (one instruction, no rotation)
+// and the cell address is base + i * (row pitch): an immediate.  The static per-visibility data come from the records
+// of k_grid_rec (kernel arguments, first-tap cell) and a plan-time table of plane weights.
+// The tile is always 48 x 48 cells here (rows / columns past TILE + W - 1 hold zeros: narrower kernels have zero
+// coefficients on lanes >= W and read, but do not use, those cells).
+constexpr int RW_LS = TILE + 16;  // cells per tile row and tile rows
+
+template <int I>
+__device__ __forceinline__ void fmac_row_bcast(double &acc, double ku, double cell)
+{
+    // acc += (ku of lane I of this lane's 16-lane row) * cell
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(ku), "v"(cell), "n"(I));
+}
+
+// planes 0, 1 are addressed from base, planes 2, 3 from base2 = base + 2 tiles: every offset is a 16-bit immediate
+template <int KP, int I>
+__device__ __forceinline__ void rw_steps(const char *base, const char *base2, double ku, double (&sr)[KP], double (&si)[KP])
+{
+    if constexpr (I < 16) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const char *bp = k < 2 ? base : base2;
+            const double2 cell = *reinterpret_cast<const double2 *>(bp + (size_t(k & 1) * RW_LS * RW_LS + size_t(I) * RW_LS) * 16);
+            fmac_row_bcast<I>(sr[k], ku, cell.x);  // (v_mul_f64 has no DPP form: the accumulators start from zero)
+            fmac_row_bcast<I>(si[k], ku, cell.y);
+        }
+        rw_steps<KP, I + 1>(base, base2, ku, sr, si);
+    }
+}
+
+// sum over the 8 lanes of this lane's half row (lanes 0..7 / 8..15 of a 16-lane row), left in every lane of the half
+__device__ __forceinline__ double half_row_sum(double v)
+{
+    auto dpp = [](double x, auto ctrl) {
+        constexpr int C = decltype(ctrl)::value;
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), C, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), C, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    };
+    v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror: lane b <-> 7 - b
+    v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    return v;
+}
+
+template <int W, int KP>
+__global__ void __launch_bounds__(MP_THREADS) k_degrid_rw(GroupArgs ga, const VisRec *__restrict__ rec,
+                                                           const double *__restrict__ kwtab, const double2 *__restrict__ grid,
+                                                           double2 *__restrict__ sacc, const double *__restrict__ swgt,
+                                                           double2 *__restrict__ pval_out)
+{
+    const PlaneArgs &a = ga.a;
+    constexpr int D = kernel_poly_degree_c(W);
+    constexpr int L = TILE + W - 1;
+    constexpr int LL = RW_LS * RW_LS;
+    extern __shared__ double lds[];
+    double2 *tiles = reinterpret_cast<double2 *>(lds);  // KP tiles of LL complex cells
+
+    const uint32_t item = blockIdx.x;
+    if (item >= a.nwork) return;
+    const WorkItem wi = a.work[item];
+    const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
+    const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = lane & 15, g = lane >> 4;
+    const int kpa = ga.kp_alloc;
+    const uint32_t stride = (MP_THREADS / 64) * 4;
+    const uint32_t jlast = wi.end - 1;
+    // first records requested before the tile: their latency hides behind the tile loads
+    uint32_t j = wi.begin + wave * 4 + g;
+    bool valid = j < wi.end;
+    auto load_z = [&](uint32_t jj) { return *reinterpret_cast<const double2 *>(rec + min(jj, jlast)); };
+    auto load_key = [&](uint32_t jj) { return rec[min(jj, jlast)].key; };
+    double2 z = load_z(j);
+    int key = load_key(j);
+    double kw[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) kw[k] = kwtab[size_t(min(j, jlast)) * size_t(kpa) + k];
+    const int bsel = (b & 7) < KP ? (b & 7) : 0;  // the plane whose value this lane writes (pval_out)
+    {
+        // every load of the thread's cells (all planes) in flight before the first LDS store
+        constexpr int NJ = (LL + MP_THREADS - 1) / MP_THREADS;
+        size_t off[NJ];
+        bool in[NJ];
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+            const int i = int(threadIdx.x) + q * MP_THREADS;
+            const int la = i / RW_LS, lb = i - la * RW_LS;
+            int gu = bu + la, gv = bv + lb;
+            gu = gu >= a.nu ? gu % a.nu : gu;
+            gv = gv >= a.nv ? gv % a.nv : gv;
+            in[q] = i < LL && la < L && lb < L;
+            off[q] = size_t(gu) * size_t(a.nv) + size_t(gv);
+        }
+        double2 v[KP][NJ];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const double2 *gk = grid + size_t(k) * ga.plane_stride;
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) v[k][q] = in[q] ? gk[off[q]] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                const int i = int(threadIdx.x) + q * MP_THREADS;
+                if (i < LL) tiles[k * LL + i] = v[k][q];
+            }
+    }
+    double c[D + 1];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) c[k] = b < W ? a.ktab[b * (D + 1) + k] : 0.0;
+    auto kernel_value = [&](double zz) {  // two independent half chains (even / odd powers)
+        const double z2 = zz * zz;
+        double e = c[D], o = c[D - 1];
+#pragma unroll
+        for (int k = D - 2; k >= 0; k -= 2) {
+            e = fma(e, z2, c[k]);
+            if (k >= 1) o = fma(o, z2, c[k - 1]);
+        }
+        return fma(o, zz, e);
+    };
+    static_assert((D & 1) == 0, "kernel_value assumes an even polynomial degree");
+    __syncthreads();
+
+    const char *tbase = reinterpret_cast<const char *>(tiles);
+    for (uint32_t jb = wi.begin + wave * 4; jb < wi.end; jb += stride) {
+        const uint32_t jn = j + stride;
+        const bool nvalid = jn < wi.end;
+        const double2 nz = load_z(jn);
+        const int nkey = load_key(jn);
+        double nkw[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) nkw[k] = kwtab[size_t(min(jn, jlast)) * size_t(kpa) + k];
+        {
+            double ku = kernel_value(z.x);
+            const double kvb = kernel_value(z.y);
+            const int lu = key >> 8, lv = key & 255;
+            // lane b takes footprint column cb = (b - lv) mod 16: its LDS column lv + cb is congruent to b mod 16 whatever
+            // the visibility, and with a row pitch of 0 mod 16 cells the 16-byte slot of every lane's read is b mod 16 -- the
+            // lane groups of a ds_read_b128 mix two visibilities, and their slots stay distinct (no bank conflicts)
+            const int cb = (b - lv) & 15;
+            const double kv = __shfl(kvb, (lane & ~15) + cb);
+            const char *base = tbase + (lu * RW_LS + lv + cb) * 16;
+            const char *base2 = base + 2 * LL * 16;
+            double sr[KP], si[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) sr[k] = si[k] = 0.0;
+            asm volatile("s_nop 1" : "+v"(ku));  // VALU write -> DPP read of the same register needs 2 wait states
+            rw_steps<KP, 0>(base, base2, ku, sr, si);
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                tr = fma(sr[k], kw[k], tr);
+                ti = fma(si[k], kw[k], ti);
+            }
+            tr *= kv;
+            ti *= kv;
+            // sum over the 16 columns: the halves of the row exchange one component, then lanes 0..7 reduce the real part
+            // and lanes 8..15 the imaginary part
+            const bool lo = b < 8;
+            const double keep = lo ? tr : ti, give = lo ? ti : tr;
+            const double tot = half_row_sum(keep + rotn_f64<8>(give));  // lanes 0..7: Re, lanes 8..15: Im
+            if (valid) {
+                if (pval_out != nullptr) {
+                    if ((b & 7) < KP) {
+                        const double wj = swgt[j];
+                        double *o = reinterpret_cast<double *>(pval_out + size_t(j) * size_t(kpa) + size_t(bsel));
+                        // ((v * swgt) * kw): the products k_scale_sorted and the scatter would form
+                        double kwl = kw[0];
+#pragma unroll
+                        for (int k = 1; k < KP; ++k) kwl = bsel == k ? kw[k] : kwl;
+                        o[lo ? 0 : 1] = (tot * wj) * kwl;
+                    }
+                } else if ((b & 7) == 0) {
+                    double *o = reinterpret_cast<double *>(sacc + j);
+                    o[lo ? 0 : 1] = tot;
+                }
+            }
+        }
+        j = jn;
+        valid = nvalid;
+        z = nz;
+        key = nkey;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) kw[k] = nkw[k];
+    }
+}
+
+// plan time: plane weights of every visibility (wmode 1 / no w-gridding, single pass), kp_alloc per visibility
+template <int W>
+__global__ void k_plane_weights(GroupArgs ga, int64_t nactive, double *__restrict__ kwtab)
+{
+    constexpr int D = kernel_poly_degree_c(W);
+    const int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (j >= nactive + REC_PAD) return;
+    const PlaneArgs &a = ga.a;
+    const double pw = (a.do_w && j < nactive) ? a.pw[j] : 0.0;
+    for (int p = 0; p < ga.kp_alloc; ++p)
+        kwtab[size_t(j) * size_t(ga.kp_alloc) + size_t(p)] =
+            (p < ga.kp && j < nactive) ? plane_weight_of<W, D>(a, a.plane + p, ga.coefk[p], pw, nullptr) : 0.0;
+}
+
+// plan time: the static half of the records (same expressions as the walk kernels evaluate per visibility)
+template <int W>
+__global__ void k_vis_records(int nu, int nv, int64_t nactive, const double *__restrict__ pu, const double *__restrict__ pv,
+                              VisRec *__restrict__ rec)
+{
+    const int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (j >= nactive + REC_PAD) return;
+    VisRec r;
+    if (j >= nactive) {  // padding: read, never used
+        r.zu = r.zv = 0.0;
+        r.blk = r.key = 0;
+        r.offu = 8 * (BLK_CELLS - 1);
+        r.offv = 8 * (24 + BLK_CELLS - 1);
+        rec[j] = r;
+        return;
+    }
+    const double shift = 1.0 - 0.5 * double(W);
+    const double u = pu[j], v = pv[j];
+    const double fu = floor(u + shift), fv = floor(v + shift);
+    r.zu = 2.0 * ((u + shift) - fu) - 1.0;
+    r.zv = 2.0 * ((v + shift) - fv) - 1.0;
+    const int lu = wrap_once((int)fu, nu) % TILE, lv = wrap_once((int)fv, nv) % TILE;
+    r.blk = ((lu >> 2) << 8) | (lv >> 2);
+    r.offu = 8 * (BLK_CELLS - 1 - (lu & 3));
+    r.offv = 8 * (24 + BLK_CELLS - 1 - (lv & 3));
+    r.key = (lu << 8) | lv;
+    rec[j] = r;
+}
+
+// per apply (outside Hessian applies): pval[j][p] = sval[j] * weight of plane p at the visibility's w
+template <int W>
+__global__ void k_plane_values(GroupArgs ga, int64_t nactive, const double2 *__restrict__ sval, double2 *__restrict__ pval)
+{
+    constexpr int D = kernel_poly_degree_c(W);
+    const int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (j >= nactive) return;
+    const PlaneArgs &a = ga.a;
+    const double2 val = sval[j];
+    const double pw = a.do_w ? a.pw[j] : 0.0;
+    for (int p = 0; p < ga.kp; ++p) {
+        const double kw = plane_weight_of<W, D>(a, a.plane + p, ga.coefk[p], pw, nullptr);
+        pval[size_t(j) * size_t(ga.kp_alloc) + size_t(p)] = make_double2(val.x * kw, val.y * kw);
+    }
+}
+
+// pval_out != NULL (single-pass plans inside a Hessian apply): instead of accumulating the model visibility into sacc,
+// lane b < KP of the visibility's row writes it multiplied by the imaging weight and by the weight of plane b --
+// the input of k_grid_rec ((v * swgt) * kw, the products k_scale_sorted and the scatter would form).
 template <int W, int KP>
 __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const double2 *__restrict__ grid,
-                                                           double2 *__restrict__ sacc)
+                                                           double2 *__restrict__ sacc, const double *__restrict__ swgt,
+                                                           double2 *__restrict__ pval_out)
 {
     const PlaneArgs &a = ga.a;
     constexpr int D = kernel_poly_degree_c(W);
@@ -500,8 +1043,15 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
             const double fu = floor(pu + shift), fv = floor(pv + shift);
             const double zu = 2.0 * ((pu + shift) - fu) - 1.0, zv = 2.0 * ((pv + shift) - fv) - 1.0;
             double ku = horner<D>(c, zu);
-            const double kv = horner<D>(c, zv);
+            const double kvb = horner<D>(c, zv);
             const int lu = wrap_once((int)fu, a.nu) - bu, lv = wrap_once((int)fv, a.nv) - bv;
+            // Lane b takes footprint column cb = (b - lv) mod 16, so its LDS column lv + cb is congruent to b mod 16
+            // whatever the visibility: with a row stride of 0 mod 16 cells the 16-byte slot of every lane's read is b mod 16.
+            // A ds_read_b128 is serviced in groups of 16 lanes that mix two DPP rows (two visibilities, lanes {0-3, 12-15} of
+            // one and {4-11} of the other): the 16 slots of a group are then always distinct -- no bank conflicts between
+            // the two footprints (they cost ~45 % of the LDS cycles with lane b on column b).
+            const int cb = (b - lv) & 15;
+            const double kv = __shfl(kvb, (lane & ~15) + cb);  // the v-kernel value of tap cb, from the lane that evaluated it
             double kw[KP];
             bool touch = false;
 #pragma unroll
@@ -509,7 +1059,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
                 kw[k] = row_bcast_f64(kwl, k);
                 touch = touch || (kw[k] != 0.0);
             }
-            const int colbase = lu * LS + lv + b;
+            const int colbase = lu * LS + lv + cb;
             int arow = b;
             double sr[KP], si[KP];
 #pragma unroll
@@ -545,7 +1095,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int off = colbase + arow * LS;
-                        if (arow < W && b < W) {
+                        if (arow < W && cb < W) {
 #pragma unroll
                             for (int k = 0; k < KP; ++k) {
                                 const double2 gval = tiles[k * LL + off];
@@ -574,7 +1124,12 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
             ti += rotn_f64<2>(ti);
             tr += rotn_f64<1>(tr);
             ti += rotn_f64<1>(ti);
-            if (b == 0 && touch) {
+            if (pval_out != nullptr) {
+                if (b < KP && valid) {
+                    const double wj = swgt[j];
+                    pval_out[size_t(j) * size_t(ga.kp_alloc) + size_t(b)] = make_double2((tr * wj) * kwl, (ti * wj) * kwl);
+                }
+            } else if (b == 0 && touch) {
                 double2 acc = sacc[j];
                 acc.x += tr;
                 acc.y += ti;

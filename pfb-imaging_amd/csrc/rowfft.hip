@@ -110,6 +110,109 @@ void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inver
 }
 
 // ---------------------------------------------------------------------------------------
+// first-axis passes with the transpose folded in (no separate k_a2b / k_b2a pass over the plane)
+// ---------------------------------------------------------------------------------------
+// grid side:   B[y][u] = IFFT_v(A[u][:])[wrap(y - ny/2, nv)]      (crop + transpose in the store)
+// degrid side: A[u][:] = FFT_v( v -> B[y(v)][u], 0 outside the image )  (pad + transpose in the load)
+// One workgroup owns one row u, so its B accesses are 16-byte pieces nu * 16 bytes apart.  What makes that
+// affordable is WHICH workgroups run together: rowmap[] hands the 8 rows of every 128-byte line of B to 8
+// workgroups that share an XCD (blockIdx equal mod 8) and are dispatched within the same 64 block ids, so the 8
+// pieces of a line meet in that XCD's L2 -- stores leave it as whole lines, loads miss once per line.
+struct CropTStore {
+    double2 *B;
+    int u, nu, ny, nv, hy;
+    __device__ __forceinline__ void operator()(int v, double2 val) const
+    {
+        int y = -1;
+        if (v < ny - hy) y = v + hy;
+        else if (v >= nv - hy) y = v - (nv - hy);
+        if (y >= 0) B[size_t(y) * size_t(nu) + size_t(u)] = val;
+    }
+};
+struct PadTLoad {
+    const double2 *B;
+    int u, nu, ny, nv, hy;
+    __device__ __forceinline__ double2 operator()(int v, int) const
+    {
+        int y = -1;
+        if (v < ny - hy) y = v + hy;
+        else if (v >= nv - hy) y = v - (nv - hy);
+        return y >= 0 ? B[size_t(y) * size_t(nu) + size_t(u)] : make_double2(0.0, 0.0);
+    }
+};
+
+template <class S>
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_a2b(const double2 *tw, const double2 *A, double2 *B,
+                                                                          const int *rowmap, int nrows, int nu, int ny)
+{
+    extern __shared__ double rf_lds[];
+    if (int(blockIdx.x) >= nrows) return;
+    const int u = rowmap[blockIdx.x];
+    PlainLoad ld{A + size_t(u) * S::N};
+    CropTStore st{B, u, nu, ny, S::N, ny / 2};
+    rf_row<S>(tw, ld, st, true, rf_lds);
+}
+
+template <class S>
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_b2a(const double2 *tw, const double2 *B, double2 *A,
+                                                                          const int *rowmap, int nrows, int nu, int ny)
+{
+    extern __shared__ double rf_lds[];
+    if (int(blockIdx.x) >= nrows) return;
+    const int u = rowmap[blockIdx.x];
+    PadTLoad ld{B, u, nu, ny, S::N, ny / 2};
+    PlainStore st{A + size_t(u) * S::N};
+    rf_row<S>(tw, ld, st, false, rf_lds);
+}
+
+template <class S>
+static void launch_a2b(const RowFFTPlan &pl, const double2 *A, double2 *B, const int *rowmap, int nrows, int nu, int ny,
+                       hipStream_t stream)
+{
+    static bool attr = false;
+    rf_allow_lds(&k_rowfft_a2b<S>, &attr);
+    hipLaunchKernelGGL((k_rowfft_a2b<S>), dim3(uint32_t(nrows)), dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, A, B,
+                       rowmap, nrows, nu, ny);
+}
+template <class S>
+static void launch_b2a(const RowFFTPlan &pl, const double2 *B, double2 *A, const int *rowmap, int nrows, int nu, int ny,
+                       hipStream_t stream)
+{
+    static bool attr = false;
+    rf_allow_lds(&k_rowfft_b2a<S>, &attr);
+    hipLaunchKernelGGL((k_rowfft_b2a<S>), dim3(uint32_t(nrows)), dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A,
+                       rowmap, nrows, nu, ny);
+}
+
+void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, const int *rowmap_dev, int nrows, int nu, int ny,
+                hipStream_t stream)
+{
+    PFB_REQUIRE(!pl.doubled, "transposing row FFT: doubled shapes are not supported");
+    switch (pl.N) {
+#define RF_X(L, K)                                                                       \
+    case (L << K): launch_a2b<RfShape<L, K>>(pl, A_dev, B_dev, rowmap_dev, nrows, nu, ny, stream); break;
+        RF_FOR_SHAPES(RF_X)
+#undef RF_X
+        default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);
+    }
+    PFB_HIP(hipGetLastError());
+}
+
+void rowfft_b2a(const RowFFTPlan &pl, const double2 *B_dev, double2 *A_dev, const int *rowmap_dev, int nrows, int nu, int ny,
+                hipStream_t stream)
+{
+    PFB_REQUIRE(!pl.doubled, "transposing row FFT: doubled shapes are not supported");
+    switch (pl.N) {
+#define RF_X(L, K)                                                                       \
+    case (L << K): launch_b2a<RfShape<L, K>>(pl, B_dev, A_dev, rowmap_dev, nrows, nu, ny, stream); break;
+        RF_FOR_SHAPES(RF_X)
+#undef RF_X
+        default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);
+    }
+    PFB_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------
 // fused second-axis passes of the plane transform
 // ---------------------------------------------------------------------------------------
 

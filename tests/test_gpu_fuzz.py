@@ -83,7 +83,7 @@ def test_edge_cases_row_fft_paths():
     one = np.zeros_like(c["mask"])
     one[7, 1] = 1
     g = Gridder(c["uvw"], c["freq"], one, **kw)  # a single visibility
-    assert g.info["nactive"] == 1 and g.info["fft_mode"] == 3
+    assert g.info["nactive"] == 1 and g.info["fft_mode"] & 3 == 3
     d = g.vis2dirty(c["vis"], c["wgt"])
     from oracle import dft
 
