@@ -63,6 +63,8 @@ __device__ __forceinline__ double nm1_of(double l, double m)
 
 struct ImgGeom {
     int nx, ny, nu, nv;
+    int bpitch;  // complex elements between consecutive rows of B
+    int apitch;  // ... of the uv-plane buffer A
     double px, py, lshift, mshift, nshift;
 };
 
@@ -327,7 +329,7 @@ __global__ void __launch_bounds__(TP * TRANSPOSE_ROWS) k_a2b(ImgGeom g, const ui
             if (u < g.nu && y < g.ny) {
                 int v = y - hy;
                 if (v < 0) v += g.nv;
-                t[k][threadIdx.x] = A[size_t(u) * g.nv + v];
+                t[k][threadIdx.x] = A[size_t(u) * size_t(g.apitch) + v];
             }
         }
         __syncthreads();
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(TP * TRANSPOSE_ROWS) k_a2b(ImgGeom g, const ui
     for (int kk = 0; kk < TP / TRANSPOSE_ROWS; ++kk) {
         const int k = int(threadIdx.y) + kk * TRANSPOSE_ROWS;
         int y = y0 + k, u = u0 + threadIdx.x;
-        if (u < g.nu && y < g.ny) B[size_t(y) * g.nu + u] = on ? t[threadIdx.x][k] : make_double2(0.0, 0.0);
+        if (u < g.nu && y < g.ny) B[size_t(y) * size_t(g.bpitch) + u] = on ? t[threadIdx.x][k] : make_double2(0.0, 0.0);
     }
 }
 
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(TP * TRANSPOSE_ROWS) k_b2a(ImgGeom g, const ui
         if (v < g.ny - hy) y = v + hy;
         else if (v >= g.nv - hy) y = v - (g.nv - hy);
         double2 val = make_double2(0.0, 0.0);
-        if (y >= 0 && u < g.nu && v < g.nv) val = B[size_t(y) * g.nu + u];
+        if (y >= 0 && u < g.nu && v < g.nv) val = B[size_t(y) * size_t(g.bpitch) + u];
         t[k][threadIdx.x] = val;
     }
     __syncthreads();
@@ -363,7 +365,7 @@ __global__ void __launch_bounds__(TP * TRANSPOSE_ROWS) k_b2a(ImgGeom g, const ui
     for (int kk = 0; kk < TP / TRANSPOSE_ROWS; ++kk) {
         const int k = int(threadIdx.y) + kk * TRANSPOSE_ROWS;
         int u = u0 + k, v = v0 + threadIdx.x;
-        if (u < g.nu && v < g.nv) A[size_t(u) * g.nv + v] = t[threadIdx.x][k];
+        if (u < g.nu && v < g.nv) A[size_t(u) * size_t(g.apitch) + v] = t[threadIdx.x][k];
     }
 }
 
@@ -391,7 +393,7 @@ __global__ void k_pad_screen_T(ImgGeom g, FusedGeom fg, const double *dcT, int d
             out.x = val;
         }
     }
-    B[size_t(y) * g.nu + u] = out;
+    B[size_t(y) * size_t(g.bpitch) + u] = out;
 }
 
 // grid side: accT[y][x] (+)= Re( B[y][wrap(x - nx/2, nu)] * exp(-2 pi i w_p t) )
@@ -402,7 +404,7 @@ __global__ void k_crop_screen_T(ImgGeom g, FusedGeom fg, const double2 *B, int d
     if (ix >= g.nx) return;
     int u = ix - g.nx / 2;
     if (u < 0) u += g.nu;
-    double2 v = B[size_t(y) * g.nu + u];
+    double2 v = B[size_t(y) * size_t(g.bpitch) + u];
     double r;
     if (do_w) {
         double ph = wplane * fg_t(fg, ix, y);
@@ -572,6 +574,7 @@ struct pfbhip_gridder {
         a.nu = int(info.nu);
         a.nv = int(info.nv);
         a.ntv = map.ntv;
+        a.apitch = geom.apitch;
         a.do_w = prm.do_wgridding;
         a.plane = plane;
         a.wmode = info.wmode;
@@ -593,9 +596,9 @@ struct pfbhip_gridder {
     {
         timer.begin(2);
         for (auto &sp : spans) {
-            double2 *rows = grid_cur + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv);
+            double2 *rows = grid_cur + size_t(k) * plane_stride + size_t(sp.row0) * size_t(geom.apitch);
             if (rowfft_v.ok) {
-                rowfft_plain(rowfft_v.pl, rows, int(sp.nrows), !forward, stream);
+                rowfft_plain(rowfft_v.pl, rows, int(sp.nrows), !forward, stream, size_t(geom.apitch));
             } else {
                 void *buf[1] = {rows};
                 PFB_ROCFFT(rocfft_execute(forward ? sp.fwd : sp.bwd, buf, nullptr, fft_info));
@@ -684,6 +687,7 @@ struct pfbhip_gridder {
     bool gather_rw = false;
     DevBuf<double> d_kw;
     float wshare[3] = {1.f / 3, 1.f / 3, 1.f / 3};  // see GroupArgs::wshare (PFBHIP_WSHARE=a,b,c overrides)
+    int stamp_mode = 0;  // PFBHIP_STAMP: 1 = record scatter, 2 = row-walk gather
     DevBuf<unsigned long long> d_stamps;  // PFBHIP_STAMP=1: in-kernel phase stamps of the record scatter (8 words per colour work item)
     DevBuf<double2> d_pval;
     template <int W, int KP>
@@ -719,7 +723,7 @@ struct pfbhip_gridder {
                 if (ga.a.nwork == 0) continue;
                 timer.begin(0);
                 if (scatter_rec) {
-                    if (d_stamps.p != nullptr) ga.dbg = d_stamps.p + (col_off[grp * 4 + size_t(col)]) * 8;
+                    if (stamp_mode == 1 && d_stamps.p != nullptr) ga.dbg = d_stamps.p + (col_off[grp * 4 + size_t(col)]) * 8;
                     switch (kp) {
                         case 1: launch_grid_rec_wk<W, 1>(ga); break;
                         case 2: launch_grid_rec_wk<W, 2>(ga); break;
@@ -770,7 +774,9 @@ struct pfbhip_gridder {
             attr_set = true;
         }
         const size_t lds = size_t(KP) * RW_LS * RW_LS * sizeof(double2);
-        hipLaunchKernelGGL((k_degrid_rw<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds, stream, ga, d_rec.p, d_kw.p, grid_cur,
+        GroupArgs gs = ga;
+        if (stamp_mode == 2 && d_stamps.p != nullptr) gs.dbg = d_stamps.p;
+        hipLaunchKernelGGL((k_degrid_rw<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds, stream, gs, d_rec.p, d_kw.p, grid_cur,
                            sacc, want_pval ? d_swgt.p : nullptr, want_pval ? d_pval.p : nullptr);
     }
     template <int W>
@@ -834,8 +840,8 @@ struct pfbhip_gridder {
     {
         for (int k = 0; k < kp; ++k)
             for (auto &sp : spans)
-                PFB_HIP(hipMemsetAsync(grid_cur + size_t(k) * plane_stride + size_t(sp.row0) * size_t(info.nv), 0,
-                                       size_t(sp.nrows) * size_t(info.nv) * sizeof(double2), st));
+                PFB_HIP(hipMemsetAsync(grid_cur + size_t(k) * plane_stride + size_t(sp.row0) * size_t(geom.apitch), 0,
+                                       size_t(sp.nrows) * size_t(geom.apitch) * sizeof(double2), st));
     }
 
     // sval (tile-sorted, weighted) -> accT, the TRANSPOSED (ny, nx) raw image (before correction)
@@ -862,7 +868,7 @@ struct pfbhip_gridder {
                 if (tfft) {
                     timer.begin(2);
                     rowfft_a2b(rowfft_v.pl, grid_cur + size_t(k) * plane_stride, d_gridB.p + size_t(k) * bstride, d_rowmap.p,
-                               int(occ_rows), int(info.nu), int(prm.ny), stream);
+                               int(occ_rows), geom.bpitch, int(prm.ny), size_t(geom.apitch), stream);
                     timer.end();
                     continue;
                 }
@@ -983,7 +989,7 @@ struct pfbhip_gridder {
                 if (tfft) {
                     timer.begin(2);
                     rowfft_b2a(rowfft_v.pl, d_gridB.p + size_t(k) * bstride, grid_cur + size_t(k) * plane_stride, d_rowmap.p,
-                               int(occ_rows), int(info.nu), int(prm.ny), stream);
+                               int(occ_rows), geom.bpitch, int(prm.ny), size_t(geom.apitch), stream);
                     timer.end();
                     continue;
                 }
@@ -1293,7 +1299,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     const int64_t ntu = ceil_div(info.nu, TILE);
     info.ntiles = ntu * m.ntv;
 
-    g->geom = ImgGeom{int(prm.nx), int(prm.ny), int(info.nu), int(info.nv), prm.pixsize_x, prm.pixsize_y,
+    g->geom = ImgGeom{int(prm.nx), int(prm.ny), int(info.nu), int(info.nv), int(info.nu), int(info.nv), prm.pixsize_x, prm.pixsize_y,
                       info.lshift, info.mshift, info.nshift};
 
     // ---- tile sort of the unmasked visibilities ----
@@ -1466,7 +1472,8 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             }
         }
         const char *stenv = std::getenv("PFBHIP_STAMP");
-        if (stenv != nullptr && stenv[0] == '1') {
+        if (stenv != nullptr && (stenv[0] == '1' || stenv[0] == '2')) {
+            g->stamp_mode = stenv[0] - '0';
             size_t nitems = 0;
             for (size_t c : g->col_cnt) nitems += c;
             g->d_stamps.alloc(std::max<size_t>(nitems, 1) * 8);
@@ -1516,7 +1523,15 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
 
     lap("kernel table + correction");
     // ---- scratch + FFT plans ----
-    g->plane_stride = size_t(info.nu) * size_t(info.nv);
+    // (row pitch of the uv-plane buffer: see the B pitch below; rocFFT row plans on A need the dense pitch)
+    {
+        RowFFTPlan probe;
+        const char *renv0 = std::getenv("PFBHIP_ROWFFT");
+        const bool own_v = !(renv0 != nullptr && renv0[0] == '0') && rowfft_make_plan(info.nv, &probe);
+        const char *aenv = std::getenv("PFBHIP_APAD");
+        g->geom.apitch = int(info.nv) + (own_v ? (aenv != nullptr ? std::max(0, std::atoi(aenv)) : 8) : 0);
+    }
+    g->plane_stride = size_t(info.nu) * size_t(g->geom.apitch);
     g->d_grid.alloc(g->plane_stride * size_t(g->kp_max));
     g->grid_cur = g->d_grid.p;
     {
@@ -1571,7 +1586,17 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     info.fft_mode = (g->rowfft_v.ok ? 1 : 0) | (g->fused ? 2 : 0) | ((!g->fused && g->rowfft_u.ok) ? 4 : 0);
     info.screen_poly = g->fgeom.npoly;
     info.scatter_mode = g->scatter_rec ? 2 : (g->scatter_blk ? 1 : 0);
-    g->bstride = size_t(prm.ny) * size_t(info.nu);
+    // Row pitch of B.  A workgroup of the transposing first-axis FFT touches B[y][u] for one u and every y: with a pitch of
+    // nu * 16 bytes (a multiple of 2^15 for every size the plan picks) all of a row's 16-byte pieces fall on one L2 /
+    // memory channel.  8 more elements (128 bytes) per row walk the channels instead (PFBHIP_BPAD overrides; the rocFFT
+    // second axis needs the dense pitch).
+    {
+        const char *benv = std::getenv("PFBHIP_BPAD");
+        const int bpad = g->fused ? (benv != nullptr ? std::max(0, std::atoi(benv)) : 8) : 0;
+        g->geom.bpitch = int(info.nu) + bpad;
+        g->fgeom.bpitch = g->geom.bpitch;
+    }
+    g->bstride = size_t(prm.ny) * size_t(g->geom.bpitch);
     g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
     g->d_accT.alloc(size_t(npix));
 
@@ -1803,7 +1828,7 @@ int pfbhip_gridder_grid_plane(pfbhip_gridder *g, const double *vis_host, const d
         for (int64_t a0 = 0; a0 < pu; a0 += 32)
             for (int64_t b0 = 0; b0 < pv; b0 += 32)
                 for (int64_t a = a0; a < std::min(a0 + 32, pu); ++a)
-                    for (int64_t b = b0; b < std::min(b0 + 32, pv); ++b) out[b * pu + a] = tmp[a * pv + b];
+                    for (int64_t b = b0; b < std::min(b0 + 32, pv); ++b) out[b * pu + a] = tmp[a * int64_t(g->geom.apitch) + b];
     });
 }
 

@@ -32,6 +32,7 @@ __host__ __device__ constexpr int kernel_poly_degree_c(int) { return 12; }
 
 struct PlaneArgs {
     int nu, nv, ntv;
+    int apitch;   // complex elements between consecutive rows of the uv-plane buffer (>= nv: padded off the power-of-two pitch)
     int do_w;
     int plane;
     int wmode;    // 0: ES kernel over equispaced planes, 1: Lagrange weights over Chebyshev nodes

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_grid_mp(GroupArgs ga, const doub
                 int gu = bu + la, gv = bv + lb;
                 gu = gu >= a.nu ? gu % a.nu : gu;
                 gv = gv >= a.nv ? gv % a.nv : gv;
-                const size_t o = (size_t(gu) * size_t(a.nv) + size_t(gv)) * 2;
+                const size_t o = (size_t(gu) * size_t(a.apitch) + size_t(gv)) * 2;
                 unsafeAtomicAdd(&gp[o], re);
                 unsafeAtomicAdd(&gp[o + 1], im);
             }
@@ -242,7 +242,7 @@ __device__ __forceinline__ void blk_tile_to_grid(const GroupArgs &ga, const Work
                     int gu = bu + la, gv = bv + lb;
                     gu = gu >= a.nu ? gu % a.nu : gu;
                     gv = gv >= a.nv ? gv % a.nv : gv;
-                    const size_t o = (size_t(gu) * size_t(a.nv) + size_t(gv)) * 2;
+                    const size_t o = (size_t(gu) * size_t(a.apitch) + size_t(gv)) * 2;
                     unsafeAtomicAdd(&gp[o], re);
                     unsafeAtomicAdd(&gp[o + 1], im);
                 }
@@ -262,7 +262,7 @@ __device__ __forceinline__ void blk_tile_to_grid(const GroupArgs &ga, const Work
         int gu = bu + la, gv = bv + lb;
         gu = gu >= a.nu ? gu % a.nu : gu;
         gv = gv >= a.nv ? gv % a.nv : gv;
-        off[j] = size_t(gu) * size_t(a.nv) + size_t(gv);
+        off[j] = size_t(gu) * size_t(a.apitch) + size_t(gv);
         lo[j] = i < L * L ? la * LS + lb : -1;
     }
     double2 v[KP][NJ];
@@ -775,6 +775,8 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_rw(GroupArgs ga, const Vi
 
     const uint32_t item = blockIdx.x;
     if (item >= a.nwork) return;
+    const bool stamp = ga.dbg != nullptr;
+    const unsigned long long ts0 = stamp ? __builtin_readcyclecounter() : 0ull;
     const WorkItem wi = a.work[item];
     const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
     const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
@@ -807,7 +809,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_rw(GroupArgs ga, const Vi
             gu = gu >= a.nu ? gu % a.nu : gu;
             gv = gv >= a.nv ? gv % a.nv : gv;
             in[q] = i < LL && la < L && lb < L;
-            off[q] = size_t(gu) * size_t(a.nv) + size_t(gv);
+            off[q] = size_t(gu) * size_t(a.apitch) + size_t(gv);
         }
         double2 v[KP][NJ];
 #pragma unroll
@@ -839,6 +841,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_rw(GroupArgs ga, const Vi
     };
     static_assert((D & 1) == 0, "kernel_value assumes an even polynomial degree");
     __syncthreads();
+    const unsigned long long ts1 = stamp ? __builtin_readcyclecounter() : 0ull;
 
     const char *tbase = reinterpret_cast<const char *>(tiles);
     for (uint32_t jb = wi.begin + wave * 4; jb < wi.end; jb += stride) {
@@ -901,6 +904,23 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_rw(GroupArgs ga, const Vi
         key = nkey;
 #pragma unroll
         for (int k = 0; k < KP; ++k) kw[k] = nkw[k];
+    }
+    if (stamp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts2 = __builtin_readcyclecounter();
+        unsigned long long *d = ga.dbg + size_t(item) * 8;
+        if (threadIdx.x == 0) {
+            d[0] = ts1 - ts0;  // tile load
+            d[1] = ts2 - ts1;  // wave 0: its rounds
+            d[2] = 0;
+            d[3] = 0;
+            d[4] = wi.end - wi.begin;
+            d[7] = wi.tile;
+        }
+        if (threadIdx.x == MP_THREADS - 64) {
+            d[5] = ts2 - ts1;  // last wave's rounds
+            d[6] = ts2 - ts0;
+        }
     }
 }
 
@@ -1007,7 +1027,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
             gu = gu >= a.nu ? gu % a.nu : gu;
             gv = gv >= a.nv ? gv % a.nv : gv;
             in[j] = i < LL && la < L && lb < L;
-            off[j] = size_t(gu) * size_t(a.nv) + size_t(gv);
+            off[j] = size_t(gu) * size_t(a.apitch) + size_t(gv);
         }
         double2 v[KP][NJ];
 #pragma unroll

@@ -27,13 +27,13 @@ struct PlainStore {
 // (512 threads -> 256 VGPRs, 640/768 -> 168, 1024 -> 128); the straight-line passes need ~165.
 // INV is a template parameter: a run-time direction costs 128 v_cndmask per row and 20 % of the rate.
 template <class S, bool INV>
-__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_plain(const double2 *tw, double2 *data, int nrows)
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_plain(const double2 *tw, double2 *data, int nrows, size_t pitch)
 {
     extern __shared__ double rf_lds[];
     const int row = blockIdx.x;
     if (row >= nrows) return;
-    PlainLoad ld{data + size_t(row) * S::N};
-    PlainStore st{data + size_t(row) * S::N};
+    PlainLoad ld{data + size_t(row) * pitch};
+    PlainStore st{data + size_t(row) * pitch};
     rf_row<S>(tw, ld, st, INV, rf_lds);
 }
 
@@ -79,28 +79,29 @@ void RowFFT::release()
 }
 
 template <class S, bool INV>
-static void launch_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, hipStream_t stream)
+static void launch_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, size_t pitch, hipStream_t stream)
 {
     static bool attr = false;
     rf_allow_lds(&k_rowfft_plain<S, INV>, &attr);
     hipLaunchKernelGGL((k_rowfft_plain<S, INV>), dim3(uint32_t(nrows)), dim3(S::T), size_t(S::LDS_BYTES), stream,
-                       pl.twiddle, data_dev, nrows);
+                       pl.twiddle, data_dev, nrows, pitch);
 }
 
-void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inverse, hipStream_t stream)
+void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inverse, hipStream_t stream, size_t pitch)
 {
+    if (pitch == 0) pitch = size_t(pl.N);
     switch (pl.N) {
 #define RF_X(L, K)                                                                  \
     case (L << K):                                                                  \
-        if (inverse) launch_plain<RfShape<L, K>, true>(pl, data_dev, nrows, stream); \
-        else launch_plain<RfShape<L, K>, false>(pl, data_dev, nrows, stream);        \
+        if (inverse) launch_plain<RfShape<L, K>, true>(pl, data_dev, nrows, pitch, stream); \
+        else launch_plain<RfShape<L, K>, false>(pl, data_dev, nrows, pitch, stream);        \
         break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X
 #define RF_X(L, K)                                                                                 \
     case 2 * (L << K):                                                                             \
-        if (inverse) launch_plain<RfShape2<RfShape<L, K>>, true>(pl, data_dev, nrows, stream);     \
-        else launch_plain<RfShape2<RfShape<L, K>>, false>(pl, data_dev, nrows, stream);            \
+        if (inverse) launch_plain<RfShape2<RfShape<L, K>>, true>(pl, data_dev, nrows, pitch, stream);     \
+        else launch_plain<RfShape2<RfShape<L, K>>, false>(pl, data_dev, nrows, pitch, stream);            \
         break;
         RF_FOR_SHAPES2(RF_X)
 #undef RF_X
@@ -143,54 +144,54 @@ struct PadTLoad {
 
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_a2b(const double2 *tw, const double2 *A, double2 *B,
-                                                                          const int *rowmap, int nrows, int nu, int ny)
+                                                                          const int *rowmap, int nrows, int nu, int ny, size_t apitch)
 {
     extern __shared__ double rf_lds[];
     if (int(blockIdx.x) >= nrows) return;
     const int u = rowmap[blockIdx.x];
-    PlainLoad ld{A + size_t(u) * S::N};
+    PlainLoad ld{A + size_t(u) * apitch};
     CropTStore st{B, u, nu, ny, S::N, ny / 2};
     rf_row<S>(tw, ld, st, true, rf_lds);
 }
 
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_b2a(const double2 *tw, const double2 *B, double2 *A,
-                                                                          const int *rowmap, int nrows, int nu, int ny)
+                                                                          const int *rowmap, int nrows, int nu, int ny, size_t apitch)
 {
     extern __shared__ double rf_lds[];
     if (int(blockIdx.x) >= nrows) return;
     const int u = rowmap[blockIdx.x];
     PadTLoad ld{B, u, nu, ny, S::N, ny / 2};
-    PlainStore st{A + size_t(u) * S::N};
+    PlainStore st{A + size_t(u) * apitch};
     rf_row<S>(tw, ld, st, false, rf_lds);
 }
 
 template <class S>
 static void launch_a2b(const RowFFTPlan &pl, const double2 *A, double2 *B, const int *rowmap, int nrows, int nu, int ny,
-                       hipStream_t stream)
+                       size_t apitch, hipStream_t stream)
 {
     static bool attr = false;
     rf_allow_lds(&k_rowfft_a2b<S>, &attr);
     hipLaunchKernelGGL((k_rowfft_a2b<S>), dim3(uint32_t(nrows)), dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, A, B,
-                       rowmap, nrows, nu, ny);
+                       rowmap, nrows, nu, ny, apitch);
 }
 template <class S>
 static void launch_b2a(const RowFFTPlan &pl, const double2 *B, double2 *A, const int *rowmap, int nrows, int nu, int ny,
-                       hipStream_t stream)
+                       size_t apitch, hipStream_t stream)
 {
     static bool attr = false;
     rf_allow_lds(&k_rowfft_b2a<S>, &attr);
     hipLaunchKernelGGL((k_rowfft_b2a<S>), dim3(uint32_t(nrows)), dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A,
-                       rowmap, nrows, nu, ny);
+                       rowmap, nrows, nu, ny, apitch);
 }
 
 void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, const int *rowmap_dev, int nrows, int nu, int ny,
-                hipStream_t stream)
+                size_t apitch, hipStream_t stream)
 {
     PFB_REQUIRE(!pl.doubled, "transposing row FFT: doubled shapes are not supported");
     switch (pl.N) {
 #define RF_X(L, K)                                                                       \
-    case (L << K): launch_a2b<RfShape<L, K>>(pl, A_dev, B_dev, rowmap_dev, nrows, nu, ny, stream); break;
+    case (L << K): launch_a2b<RfShape<L, K>>(pl, A_dev, B_dev, rowmap_dev, nrows, nu, ny, apitch, stream); break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);
@@ -199,12 +200,12 @@ void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, cons
 }
 
 void rowfft_b2a(const RowFFTPlan &pl, const double2 *B_dev, double2 *A_dev, const int *rowmap_dev, int nrows, int nu, int ny,
-                hipStream_t stream)
+                size_t apitch, hipStream_t stream)
 {
     PFB_REQUIRE(!pl.doubled, "transposing row FFT: doubled shapes are not supported");
     switch (pl.N) {
 #define RF_X(L, K)                                                                       \
-    case (L << K): launch_b2a<RfShape<L, K>>(pl, B_dev, A_dev, rowmap_dev, nrows, nu, ny, stream); break;
+    case (L << K): launch_b2a<RfShape<L, K>>(pl, B_dev, A_dev, rowmap_dev, nrows, nu, ny, apitch, stream); break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
     uint64_t mask = 0;
     rf_for_each_load<S>(int(threadIdx.x), [&](int u, int slot) { mask |= (occ[u >> 5] ? 1ull : 0ull) << slot; });
     for (int k = 0; k < planes.kp; ++k) {
-        OccLoad ld{B + size_t(k) * bstride + size_t(y) * g.nu, mask};
+        OccLoad ld{B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch), mask};
         double re[S::E], im[S::E];
         int t;
         rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
         int t;
         rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
         rf_opaque(t);
-        double2 *brow = B + size_t(k) * bstride + size_t(y) * g.nu;
+        double2 *brow = B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch);
 #pragma unroll
         for (int e = 0; e < S::E; ++e)
             if ((omask >> e) & 1u) brow[S::out_pos(t, e)] = make_double2(re[e], im[e]);
@@ -457,7 +458,7 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
     rf_for_each_load<S1>(int(threadIdx.x), [&](int pos, int slot) { mask |= (occ[(2 * pos) >> 5] ? 1u : 0u) << slot; });
     const double2 *__restrict__ tw2 = tw + S1::N;
     for (int k = 0; k < planes.kp; ++k) {
-        const double2 *row = B + size_t(k) * bstride + size_t(y) * g.nu;
+        const double2 *row = B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch);
         OccLoad2 ld_e{row, mask, 0}, ld_o{row, mask, 1};
         double er[S1::E], ei[S1::E], orr[S1::E], oi[S1::E];
         int t;
@@ -539,7 +540,7 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
         rf_row_compute<S1>(tw, ld_o, false, rf_lds, t, orr, oi);
         __builtin_amdgcn_sched_barrier(0);
         rf_opaque(t);
-        double2 *brow = B + size_t(k) * bstride + size_t(y) * g.nu;
+        double2 *brow = B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch);
 #pragma unroll
         for (int e = 0; e < S1::E; ++e) {
             const int k1 = S1::out_pos(t, e);

@@ -16,20 +16,23 @@ struct RowFFT {
     ~RowFFT() { release(); }
 };
 
-void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inverse, hipStream_t stream);
+// pitch: complex elements between consecutive rows (0: dense, = the row length)
+void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inverse, hipStream_t stream, size_t pitch = 0);
 
 // First-axis transforms of the occupied rows of A (nu, nv = pl.N) with the crop / pad + transpose folded into the store /
-// load: rowmap_dev[b] is the row of workgroup b (see rowfft.hip: the 8 rows of a 128-byte line of B share an XCD).
+// load: rowmap_dev[b] is the row of workgroup b (see rowfft.hip: the 8 rows of a 128-byte line of B share an XCD); nu here is the
+// row pitch of B, apitch that of A (complex elements).
 //   a2b: B[y][u] = IFFT_v(A[u][:])[wrap(y - ny/2)]   b2a: A[u][:] = FFT_v(v -> B[y(v)][u], 0 outside the image)
 void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, const int *rowmap_dev, int nrows, int nu, int ny,
-                hipStream_t stream);
+                size_t apitch, hipStream_t stream);
 void rowfft_b2a(const RowFFTPlan &pl, const double2 *B_dev, double2 *A_dev, const int *rowmap_dev, int nrows, int nu, int ny,
-                hipStream_t stream);
+                size_t apitch, hipStream_t stream);
 
 // Geometry of the second-axis (u) pass of the gridder's plane transform.
 constexpr int FUSED_MAXPOLY = 20;
 struct FusedGeom {
     int nx, ny, nu;
+    int bpitch;  // complex elements between consecutive rows of B (>= nu; padded off the power-of-two pitch, see gridder.hip)
     double px, py, lshift, mshift, nshift;
     // n - 1 = sqrt(1 - r2) - 1 as a polynomial in s = r2 * za + zb in [-1, 1] (npoly coefficients, highest
     // first); npoly = 0: evaluate the square root (wide fields).  Filled by fused_geom_fit().

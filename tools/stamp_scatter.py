@@ -34,16 +34,18 @@ b = buf.astype(np.float64)
 b = b[b[:, 4] > 0]
 tot = b[:, 0] + b[:, 1] + b[:, 2] + b[:, 3]
 print(f"{len(b)} items, scatter_mode {g.info['scatter_mode']}; cycles summed over items (wave 0's view):")
-for i, name in enumerate(["prologue", "vis loop (wave 0)", "barrier wait (wave 0)", "tile flush"]):
+names = ["prologue", "vis loop (wave 0)", "barrier wait (wave 0)", "tile flush"] if os.environ["PFBHIP_STAMP"] == "1" else ["tile load", "rounds (wave 0)", "-", "-"]
+for i, name in enumerate(names):
     print(f"  {name:24s} {b[:, i].sum() / tot.sum() * 100:5.1f} %   mean {b[:, i].mean():9.0f} cycles")
-print(f"  last wave loop mean {b[:, 5].mean():9.0f}, wait {b[:, 6].mean():9.0f}")
+print(f"  last wave loop mean {b[:, 5].mean():9.0f}, wait / total {b[:, 6].mean():9.0f}")
+nw = 12 if os.environ["PFBHIP_STAMP"] == "1" else 16
 print(f"  vis per item mean {b[:, 4].mean():.0f}; cycles per visibility of a wave's share: "
-      f"{(b[:, 1] / np.maximum(b[:, 4] / 12, 1)).mean():.0f} (mean over items), "
-      f"{b[:, 1].sum() / (b[:, 4].sum() / 12):.0f} (weighted)")
+      f"{(b[:, 1] / np.maximum(b[:, 4] / nw, 1)).mean():.0f} (mean over items), "
+      f"{b[:, 1].sum() / (b[:, 4].sum() / nw):.0f} (weighted)")
 for lo, hi in [(1, 64), (64, 256), (256, 1024), (1024, 4097)]:
     m = (b[:, 4] >= lo) & (b[:, 4] < hi)
     if m.any():
         print(f"  items with {lo:4d}..{hi:4d} vis: {m.sum():6d}  share of cycles {tot[m].sum() / tot.sum() * 100:5.1f} %  "
               f"prologue {b[m, 0].mean():7.0f} loop {b[m, 1].mean():8.0f} wait {b[m, 2].mean():7.0f} flush {b[m, 3].mean():7.0f}  "
-              f"cycles/vis/wave {(b[m, 1].sum() / (b[m, 4].sum() / 12)):.0f}")
+              f"cycles/vis/wave {(b[m, 1].sum() / (b[m, 4].sum() / nw)):.0f}")
 g.close()
