@@ -916,8 +916,11 @@ struct pfbhip_gridder {
 
     FusedGeom fgeom;  // filled once by create_impl (fused path)
     const FusedGeom &fused_geom() const { return fgeom; }
+    std::vector<FusedPlanes> plane_groups;  // per pass of kp_max planes: w and the composite screen polynomials (plan time)
     FusedPlanes fused_planes(int p0, int kp) const
     {
+        const size_t grp = size_t(p0 / kp_max);
+        if (grp < plane_groups.size() && plane_groups[grp].kp == kp) return plane_groups[grp];
         FusedPlanes fp;
         fp.kp = kp;
         for (int k = 0; k < FUSED_MAXPLANES; ++k) fp.w[k] = k < kp ? wplanes[size_t(p0 + k)] : 0.0;
@@ -1582,6 +1585,20 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         fg.nshift = info.nshift;
         if (prm.do_wgridding) fused_geom_fit(fg);
         if (prm.verbosity > 0) fprintf(stderr, "[pfbhip] w-screen: n-1 polynomial with %d coefficients\n", fg.npoly);
+    }
+    g->plane_groups.clear();
+    if (g->fused) {
+        const char *penv = std::getenv("PFBHIP_SCREENPOLY");
+        const bool want = !(penv != nullptr && penv[0] == '0');
+        for (int p0 = 0; p0 < info.nplanes; p0 += g->kp_max) {
+            FusedPlanes fp;
+            fp.kp = int(std::min<int64_t>(g->kp_max, info.nplanes - p0));
+            for (int k = 0; k < FUSED_MAXPLANES; ++k) fp.w[k] = k < fp.kp ? g->wplanes[size_t(p0 + k)] : 0.0;
+            if (want && prm.do_wgridding) fused_planes_fit(g->fgeom, fp);
+            g->plane_groups.push_back(fp);
+        }
+        if (prm.verbosity > 0 && !g->plane_groups.empty())
+            fprintf(stderr, "[pfbhip] w-screen: composite cos/sin polynomials with %d coefficients\n", g->plane_groups[0].nsc);
     }
     info.fft_mode = (g->rowfft_v.ok ? 1 : 0) | (g->fused ? 2 : 0) | ((!g->fused && g->rowfft_u.ok) ? 4 : 0);
     info.screen_poly = g->fgeom.npoly;

@@ -231,7 +231,7 @@ struct OccLoad {
 
 // lds_row: the kernel keeps the running sum over the launch's planes of its image row in LDS (nx doubles
 // behind the transpose buffer) and touches accT once; otherwise (no room) every plane read-modify-writes accT.
-template <class S>
+template <class S, bool SC>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(const double2 *tw, FusedGeom g, const uint8_t *occ,
                                                           const double2 *B, size_t bstride, FusedPlanes planes,
                                                           int do_w, int first, int lds_row, double *accT, FusedFinal fin)
@@ -249,6 +249,14 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
         rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
         rf_opaque(t);
         const double wk = planes.w[k];
+        double cc[FUSED_SCMAX], ss[FUSED_SCMAX];  // SC: this plane's composite screen polynomials
+        if constexpr (SC) {
+#pragma unroll
+            for (int q = 0; q < FUSED_SCMAX; ++q) {
+                cc[q] = planes.cs[k][q];
+                ss[q] = planes.sn[k][q];
+            }
+        }
         const bool last = k == planes.kp - 1;
         // what must be added to this plane's value: the LDS running sum (thread-private cells, no barrier)
         // and / or the image so far
@@ -283,10 +291,14 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
                 if (ix >= 0) {
                     double r = im[e];  // inverse transform: value = (im, re)
                     if (do_w) {
-                        double ph = wk * fg_t(g, ix, y);
-                        ph -= rint(ph);
                         double s, c;
-                        fg_sincos2pi(ph, s, c);
+                        if constexpr (SC) {
+                            fg_screen_poly(g, cc, ss, ix, y, s, c);
+                        } else {
+                            double ph = wk * fg_t(g, ix, y);
+                            ph -= rint(ph);
+                            fg_sincos2pi(ph, s, c);
+                        }
                         r = im[e] * c + re[e] * s;  // Re( (im + i re) * (c - i s) )
                     }
                     r += old[e - e0];
@@ -309,11 +321,14 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
     }
 }
 
-struct PadLoad {
+template <bool SC>
+struct PadLoadT {
     const double *drow;  // dcT row y (or, prep: the caller's image row)
     const double *crow, *brow;  // prep: correction / beam rows (crow == NULL: drow is already prepared)
     double *lrow;        // LDS copy of the row (NULL: none); plane 0 fills it, the others read it
     const FusedGeom &g;  // the kernel argument itself (a copy would put the coefficient array in scratch)
+    const double (&cc)[FUSED_SCMAX];  // SC: the plane's composite screen polynomials (registers of the kernel)
+    const double (&ss)[FUSED_SCMAX];
     int y, do_w, k;
     double wk;
     __device__ __forceinline__ double2 operator()(int u, int) const
@@ -332,15 +347,21 @@ struct PadLoad {
             if (lrow != nullptr) lrow[ix] = val;  // thread-private cell: the same thread asks for it on every plane
         }
         if (!do_w) return make_double2(val, 0.0);
-        double ph = wk * fg_t(g, ix, y);
-        ph -= rint(ph);
         double s, c;
-        fg_sincos2pi(ph, s, c);
+        if constexpr (SC) {
+            fg_screen_poly(g, cc, ss, ix, y, s, c);
+        } else {
+            double ph = wk * fg_t(g, ix, y);
+            ph -= rint(ph);
+            fg_sincos2pi(ph, s, c);
+        }
         return make_double2(val * c, val * s);
     }
 };
 
-template <class S>
+using PadLoad = PadLoadT<false>;
+
+template <class S, bool SC>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const double2 *tw, FusedGeom g, const uint8_t *occ,
                                                          const double *dcT, FusedPrep prep, FusedPlanes planes, int do_w,
                                                          int lds_row, double2 *B, size_t bstride)
@@ -353,8 +374,14 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
     for (int e = 0; e < S::E; ++e) omask |= (occ[S::out_pos(int(threadIdx.x), e) >> 5] ? 1u : 0u) << e;
     for (int k = 0; k < planes.kp; ++k) {
         const size_t ro = size_t(y) * size_t(g.nx);
-        PadLoad ld{prep.x != nullptr ? prep.x + ro : dcT + ro, prep.x != nullptr ? prep.corr + ro : nullptr,
-                   (prep.x != nullptr && prep.beam != nullptr) ? prep.beam + ro : nullptr, lrow, g, y, do_w, k, planes.w[k]};
+        double cc[FUSED_SCMAX], ss[FUSED_SCMAX];
+#pragma unroll
+        for (int q = 0; q < FUSED_SCMAX; ++q) {
+            cc[q] = SC ? planes.cs[k][q] : 0.0;
+            ss[q] = SC ? planes.sn[k][q] : 0.0;
+        }
+        PadLoadT<SC> ld{prep.x != nullptr ? prep.x + ro : dcT + ro, prep.x != nullptr ? prep.corr + ro : nullptr,
+                        (prep.x != nullptr && prep.beam != nullptr) ? prep.beam + ro : nullptr, lrow, g, cc, ss, y, do_w, k, planes.w[k]};
         double re[S::E], im[S::E];
         int t;
         rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
@@ -428,6 +455,87 @@ void fused_geom_fit(FusedGeom &g)
         worst = std::max(worst, fabsl((long double)acc - f((long double)z)));
     }
     if (worst <= 4e-16L * fmax) g = trial;
+}
+
+void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl)
+{
+    pl.nsc = 0;
+    if (g.npoly <= 0 || pl.kp <= 0) return;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    const long double zmax = 2.0L / (long double)g.za;  // s = r2 * za - 1, r2 in [0, zmax]
+    auto tfun = [&](long double z) { return -z / (1.0L + sqrtl(1.0L - z)) + (long double)g.nshift; };
+    const int M = 64;
+    int need = 0;
+    std::vector<std::vector<long double>> mono(size_t(2 * pl.kp));
+    for (int k = 0; k < pl.kp; ++k)
+        for (int part = 0; part < 2; ++part) {
+            std::vector<long double> fv(M), c(M, 0.0L);
+            for (int j = 0; j < M; ++j) {
+                const long double z = 0.5L * zmax * (cosl(pi * (j + 0.5L) / M) + 1.0L);
+                long double ph = (long double)pl.w[k] * tfun(z);
+                ph -= rintl(ph);
+                fv[size_t(j)] = part == 0 ? cosl(2.0L * pi * ph) : sinl(2.0L * pi * ph);
+            }
+            for (int q = 0; q < M; ++q) {
+                long double acc = 0.0L;
+                for (int j = 0; j < M; ++j) acc += fv[size_t(j)] * cosl(pi * q * (j + 0.5L) / M);
+                c[size_t(q)] = acc * (q == 0 ? 1.0L : 2.0L) / M;
+            }
+            int deg = -1;
+            for (int d = 0; d < FUSED_SCMAX; ++d) {
+                long double tail = 0.0L;
+                for (int q = d + 1; q < M / 2; ++q) tail += fabsl(c[size_t(q)]);
+                if (tail <= 2e-17L) { deg = d; break; }
+            }
+            if (deg < 0) return;  // phase too large for a short polynomial: general path
+            need = std::max(need, deg + 1);
+            // Chebyshev -> monomial in s
+            std::vector<long double> mo(size_t(deg + 1), 0.0L), t0(size_t(deg + 1), 0.0L), t1(size_t(deg + 1), 0.0L);
+            t0[0] = 1.0L;
+            if (deg >= 1) t1[1] = 1.0L;
+            for (int q = 0; q <= deg; ++q) {
+                const std::vector<long double> &tq = q == 0 ? t0 : t1;
+                for (int i = 0; i <= deg; ++i) mo[size_t(i)] += c[size_t(q)] * tq[size_t(i)];
+                if (q >= 1) {
+                    std::vector<long double> t2(size_t(deg + 1), 0.0L);
+                    for (int i = 0; i < deg; ++i) t2[size_t(i + 1)] = 2.0L * t1[size_t(i)];
+                    for (int i = 0; i <= deg; ++i) t2[size_t(i)] -= t0[size_t(i)];
+                    t0 = t1;
+                    t1 = t2;
+                }
+            }
+            mono[size_t(2 * k + part)] = mo;
+        }
+    if (need > FUSED_SCMAX) return;
+    need = FUSED_SCMAX;  // the kernels evaluate a fixed number of coefficients (leading zeros)
+    FusedPlanes trial = pl;
+    trial.nsc = need;
+    for (int k = 0; k < pl.kp; ++k)
+        for (int part = 0; part < 2; ++part) {
+            const auto &mo = mono[size_t(2 * k + part)];
+            double *dst = part == 0 ? trial.cs[k] : trial.sn[k];
+            for (int i = 0; i < need; ++i) {  // highest power first, padded with leading zeros
+                const int power = need - 1 - i;
+                dst[i] = power < int(mo.size()) ? double(mo[size_t(power)]) : 0.0;
+            }
+        }
+    // verify in double arithmetic, as the kernel evaluates it
+    long double worst = 0.0L;
+    const int NS = 2049;
+    for (int k = 0; k < pl.kp; ++k)
+        for (int j = 0; j < NS; ++j) {
+            const double z = double(zmax * j / (NS - 1));
+            const double sv = z * g.za + g.zb;
+            double cc = trial.cs[k][0], ss = trial.sn[k][0];
+            for (int i = 1; i < need; ++i) {
+                cc = cc * sv + trial.cs[k][i];
+                ss = ss * sv + trial.sn[k][i];
+            }
+            long double ph = (long double)pl.w[k] * tfun((long double)z);
+            worst = std::max(worst, fabsl((long double)cc - cosl(2.0L * pi * ph)));
+            worst = std::max(worst, fabsl((long double)ss - sinl(2.0L * pi * ph)));
+        }
+    if (worst <= 4e-16L) pl = trial;
 }
 
 // ---- doubled shapes (N = 2 N1): dedicated fused kernels ---------------------------------------------------
@@ -529,9 +637,10 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
     }
     const double2 *__restrict__ tw2 = tw + S1::N;
     const size_t ro = size_t(y) * size_t(g.nx);
+    const double zc[FUSED_SCMAX] = {};  // (the doubled shapes evaluate the screen the general way)
     for (int k = 0; k < planes.kp; ++k) {
         PadLoad base{prep.x != nullptr ? prep.x + ro : dcT + ro, prep.x != nullptr ? prep.corr + ro : nullptr,
-                     (prep.x != nullptr && prep.beam != nullptr) ? prep.beam + ro : nullptr, nullptr, g, y, do_w, k, planes.w[k]};
+                     (prep.x != nullptr && prep.beam != nullptr) ? prep.beam + ro : nullptr, nullptr, g, zc, zc, y, do_w, k, planes.w[k]};
         PadLoad2 ld_e{base, 0}, ld_o{base, 1};
         double er[S1::E], ei[S1::E], orr[S1::E], oi[S1::E];
         int t;
@@ -588,11 +697,17 @@ static void launch_crop(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t 
                         size_t bstride, const FusedPlanes &planes, int do_w, bool first, double *accT_dev,
                         const FusedFinal &fin, hipStream_t stream)
 {
-    static bool attr = false;
-    rf_allow_lds(&k_fused_fft_crop<S>, &attr);
+    static bool attr = false, attr_sc = false;
     const bool row = fused_row_fits(S::LDS_BYTES, g.nx) && planes.kp > 1;
     const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
-    hipLaunchKernelGGL(k_fused_fft_crop<S>, dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
+    if (planes.nsc > 0 && do_w) {
+        rf_allow_lds(&k_fused_fft_crop<S, true>, &attr_sc);
+        hipLaunchKernelGGL((k_fused_fft_crop<S, true>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
+                           bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin);
+        return;
+    }
+    rf_allow_lds(&k_fused_fft_crop<S, false>, &attr);
+    hipLaunchKernelGGL((k_fused_fft_crop<S, false>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
                        bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin);
 }
 
@@ -601,11 +716,17 @@ static void launch_pad(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *
                        const FusedPrep &prep, const FusedPlanes &planes, int do_w, double2 *B_dev, size_t bstride,
                        hipStream_t stream)
 {
-    static bool attr = false;
-    rf_allow_lds(&k_fused_pad_fft<S>, &attr);
+    static bool attr = false, attr_sc = false;
     const bool row = fused_row_fits(S::LDS_BYTES, g.nx) && planes.kp > 1;
     const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
-    hipLaunchKernelGGL(k_fused_pad_fft<S>, dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
+    if (planes.nsc > 0 && do_w) {
+        rf_allow_lds(&k_fused_pad_fft<S, true>, &attr_sc);
+        hipLaunchKernelGGL((k_fused_pad_fft<S, true>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
+                           prep, planes, do_w, row ? 1 : 0, B_dev, bstride);
+        return;
+    }
+    rf_allow_lds(&k_fused_pad_fft<S, false>, &attr);
+    hipLaunchKernelGGL((k_fused_pad_fft<S, false>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
                        prep, planes, do_w, row ? 1 : 0, B_dev, bstride);
 }
 

@@ -55,10 +55,20 @@ struct FusedFinal {
     double *out = nullptr;
 };
 constexpr int FUSED_MAXPLANES = 4;
+constexpr int FUSED_SCMAX = 8;  // coefficients of a composite screen polynomial (the kernels always evaluate all of them)
 struct FusedPlanes {
     int kp;
     double w[FUSED_MAXPLANES];  // w of each plane (wavelengths)
+    // Narrow fields / small w: cos and sin of the w-screen phase 2 pi w_k (n - 1 + nshift) are themselves low-degree
+    // polynomials in s = r2 * za + zb (the abscissa of FusedGeom's n - 1 polynomial): FUSED_SCMAX coefficients each, highest
+    // first (leading zeros), fitted and verified to 4e-16 by fused_planes_fit() (nsc = FUSED_SCMAX); nsc = 0: evaluate
+    // n - 1, then sincos (the general path).
+    int nsc = 0;
+    double cs[FUSED_MAXPLANES][FUSED_SCMAX] = {};
+    double sn[FUSED_MAXPLANES][FUSED_SCMAX] = {};
 };
+// Fills pl.nsc / cs / sn for the planes pl.w[0..kp) over the field of view of g (g.npoly > 0 required), or leaves nsc = 0.
+void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl);
 
 // grid side: for every image row y and every plane k < kp: inverse row FFT of B_k[y][:] (blocks of 32
 // columns that are not occupied are taken as zero without being read), then
@@ -122,6 +132,24 @@ __device__ __forceinline__ void fg_sincos2pi(double r, double &sn, double &cs)
     pc = 0.5 - pc * x2;                           // 2!
     const double c0 = 1.0 - x2 * pc;
     cs = fold ? -c0 : c0;
+}
+
+// cos / sin of the screen phase at pixel (ix, iy) from a plane's composite polynomials (FusedPlanes::nsc > 0; the caller
+// holds the plane's coefficients in registers)
+__device__ __forceinline__ void fg_screen_poly(const FusedGeom &g, const double (&cc)[FUSED_SCMAX], const double (&ss)[FUSED_SCMAX],
+                                               int ix, int iy, double &sn, double &cs)
+{
+    const double l = g.lshift + double(ix - g.nx / 2) * g.px;
+    const double m = g.mshift + double(iy - g.ny / 2) * g.py;
+    const double sv = (l * l + m * m) * g.za + g.zb;
+    double c = cc[0], s = ss[0];
+#pragma unroll
+    for (int j = 1; j < FUSED_SCMAX; ++j) {
+        c = c * sv + cc[j];
+        s = s * sv + ss[j];
+    }
+    cs = c;
+    sn = s;
 }
 
 // image column of uv-column u (-1: u lies in the zero padding)
