@@ -47,6 +47,10 @@ int pfbhip_thread_pool_size(void);
 int64_t pfbhip_good_size(int64_t n, int real);
 
 /* ---- device memory (for device-resident callers: on-device CG, bench) ---- */
+/* 64-bit content hash of a whole host buffer (multi-threaded, memory-bandwidth bound).  The Python layer keys its
+ * plan caches on it: the reference's ducc0 calls are stateless (operators/gridder.py:590-613), so a cached plan is
+ * reused only for byte-identical uvw / freq / mask / weights / psfhat. */
+uint64_t pfbhip_hash64(const void *data_host, size_t nbytes);
 int pfbhip_malloc(void **ptr_dev, size_t bytes);
 int pfbhip_free(void *ptr_dev);
 int pfbhip_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
@@ -278,6 +282,15 @@ int pfbhip_box_sum_counts(const double *counts_host, int64_t ncorr, int64_t nx, 
 /* filter_extreme_counts (utils/weighting.py:212-226): positive counts below median(positive)/level are
  * raised to that value, in place; the median is returned through median_out (may be NULL). */
 int pfbhip_filter_extreme_counts(double *counts_host, int64_t n, double level, double *median_out);
+/* The imaging-weight chain of image_data_products (operators/gridder.py:534-576) as ONE device pipeline:
+ * _compute_counts on the (nx, ny) padded uv-grid -> filter_extreme_counts(level; <= 0 skips) -> box_sum_counts(npix_super)
+ * -> Briggs scaling counts * (5 * 10^-robust)^2 * sum(c)/sum(c^2) + 1 (robust > -2) -> weight /= counts[cell].
+ * wgt_host (ncorr, nrow, nchan) is updated in place (left untouched when every count is zero); the final counts
+ * come back through counts_out_host (ncorr, nx, ny) when it is not NULL.  One upload of uvw / freq / mask / weights. */
+int pfbhip_imaging_weights(const double *uvw_host, const double *freq_host, const uint8_t *mask_host, double *wgt_host,
+                           int64_t ncorr, int64_t nrow, int64_t nchan, int64_t nx, int64_t ny, double cell_x, double cell_y,
+                           double usign, double vsign, double robust, double filter_level, int64_t npix_super,
+                           double *counts_out_host);
 
 /* ---- wavelet dictionary Psi and the l21 / positivity proxes ---------------- */
 /*

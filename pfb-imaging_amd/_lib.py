@@ -61,7 +61,7 @@ class CGInfo(ct.Structure):
 SYMBOLS = (
     "pfbhip_last_error", "pfbhip_device_count", "pfbhip_set_device", "pfbhip_get_device", "pfbhip_device_name",
     "pfbhip_mem_info", "pfbhip_resize_thread_pool", "pfbhip_thread_pool_size", "pfbhip_good_size",
-    "pfbhip_malloc", "pfbhip_free", "pfbhip_memcpy_h2d", "pfbhip_memcpy_d2h", "pfbhip_memcpy_d2d", "pfbhip_memset",
+    "pfbhip_hash64", "pfbhip_malloc", "pfbhip_free", "pfbhip_memcpy_h2d", "pfbhip_memcpy_d2h", "pfbhip_memcpy_d2d", "pfbhip_memset",
     "pfbhip_synchronize",
     "pfbhip_gridder_create", "pfbhip_gridder_destroy", "pfbhip_gridder_get_info", "pfbhip_gridder_get_binmap",
     "pfbhip_gridder_get_planes",
@@ -78,7 +78,7 @@ SYMBOLS = (
     "pfbhip_psfconv_create", "pfbhip_psfconv_destroy", "pfbhip_psfconv_set_psfhat", "pfbhip_psfconv_set_beam",
     "pfbhip_psfconv_apply", "pfbhip_psfconv_apply_dev", "pfbhip_psfconv_cg",
     "pfbhip_uvcell_index", "pfbhip_compute_counts", "pfbhip_counts_divide", "pfbhip_box_sum_counts",
-    "pfbhip_filter_extreme_counts",
+    "pfbhip_filter_extreme_counts", "pfbhip_imaging_weights",
     "pfbhip_comm_unique_id", "pfbhip_comm_create", "pfbhip_comm_destroy", "pfbhip_comm_reduce_sum",
     "pfbhip_comm_allreduce_sum", "pfbhip_comm_barrier",
 )
@@ -101,6 +101,8 @@ def lib():
         L.pfbhip_good_size.restype = i64
         L.pfbhip_good_size.argtypes = [i64, cint]
         L.pfbhip_thread_pool_size.restype = cint
+        L.pfbhip_hash64.restype = ct.c_uint64
+        L.pfbhip_hash64.argtypes = [ct.c_void_p, ct.c_size_t]
         _lib = L
     return _lib
 
@@ -186,3 +188,43 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+_ro_memo = {}  # (address, shape, dtype) -> (array kept alive, key): read-only inputs only
+_RO_MEMO_MAX = 32
+
+
+def _immutable(a):
+    """True if nothing can write to ``a``'s memory through numpy: it and every ndarray it is a view of are read-only
+    (the form in which Ray hands out pinned inputs, operators/band_worker.py:61-106 of the reference)."""
+    obj = a
+    while isinstance(obj, np.ndarray):
+        if obj.flags.writeable:
+            return False
+        obj = obj.base
+    return True
+
+
+def content_key(a):
+    """(shape, dtype, 64-bit hash of EVERY byte) of a host array, or None: the plan-cache key component for an input.
+
+    The stateless ducc0-style calls may reuse a cached plan only for byte-identical inputs; a sampled fingerprint keyed on
+    the address misses in-place edits and reallocations at the same address.  The hash (pfbhip_hash64, multi-threaded)
+    costs a pass over the array per call; arrays that cannot change -- read-only views all the way down -- are hashed once
+    and remembered by address for as long as the memo keeps them alive."""
+    if a is None:
+        return None
+    a = np.asarray(a)
+    ro = a.flags.c_contiguous and _immutable(a)
+    if ro:
+        mk = (a.ctypes.data, a.shape, a.dtype.str)
+        hit = _ro_memo.get(mk)
+        if hit is not None:
+            return hit[1]
+    c = np.ascontiguousarray(a)
+    key = (c.shape, c.dtype.str, int(lib().pfbhip_hash64(c.ctypes.data_as(ct.c_void_p), ct.c_size_t(c.nbytes))))
+    if ro:
+        while len(_ro_memo) >= _RO_MEMO_MAX:
+            _ro_memo.pop(next(iter(_ro_memo)))
+        _ro_memo[mk] = (a, key)  # holding `a` keeps its buffer from being freed and the address from being reused
+    return key

@@ -2,10 +2,13 @@
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "common.hpp"
 
@@ -91,6 +94,66 @@ int pfbhip_resize_thread_pool(int nthreads)
 int pfbhip_thread_pool_size(void) { return g_pool_size; }
 
 int64_t pfbhip_good_size(int64_t n, int real) { return good_size(n, real != 0); }
+
+// Whole-array content hash of a HOST buffer (plan-cache keys of the stateless ducc0-style calls: the reference's calls
+// are stateless, so a cached plan may be reused only for byte-identical inputs).  Position-dependent 64-bit mix of every
+// 8-byte word, chunks hashed by a few threads (memory-bandwidth bound: ~2 ms for the 80 MB weights of a 1e7-visibility band).
+uint64_t pfbhip_hash64(const void *data_host, size_t nbytes)
+{
+    const unsigned char *p = static_cast<const unsigned char *>(data_host);
+    if (p == nullptr || nbytes == 0) return 0x9E3779B97F4A7C15ull;
+    const size_t nwords = nbytes / 8;
+    const size_t chunk = size_t(1) << 20;  // words per chunk (8 MiB)
+    const size_t nchunks = (nwords + chunk - 1) / chunk;
+    std::vector<uint64_t> part(nchunks ? nchunks : 1, 0);
+    auto mix = [](uint64_t h) {
+        h ^= h >> 33;
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 33;
+        h *= 0xc4ceb9fe1a85ec53ull;
+        h ^= h >> 33;
+        return h;
+    };
+    auto work = [&](size_t c0, size_t c1) {
+        for (size_t c = c0; c < c1; ++c) {
+            const size_t w0 = c * chunk, w1 = std::min(nwords, w0 + chunk);
+            uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, k = 2 * uint64_t(w0) + 1;
+            size_t i = w0;
+            for (; i + 4 <= w1; i += 4) {  // four independent lanes; odd multipliers k, k+2, ... make the sum position-dependent
+                uint64_t a, b, cc, d;
+                std::memcpy(&a, p + 8 * i, 8);
+                std::memcpy(&b, p + 8 * i + 8, 8);
+                std::memcpy(&cc, p + 8 * i + 16, 8);
+                std::memcpy(&d, p + 8 * i + 24, 8);
+                s0 += (a ^ 0x9E3779B97F4A7C15ull) * k;
+                s1 += (b ^ 0x9E3779B97F4A7C15ull) * (k + 2);
+                s2 += (cc ^ 0x9E3779B97F4A7C15ull) * (k + 4);
+                s3 += (d ^ 0x9E3779B97F4A7C15ull) * (k + 6);
+                k += 8;
+            }
+            for (; i < w1; ++i) {
+                uint64_t a;
+                std::memcpy(&a, p + 8 * i, 8);
+                s0 += (a ^ 0x9E3779B97F4A7C15ull) * k;
+                k += 2;
+            }
+            part[c] = mix(s0) ^ mix(s1 + 1) ^ mix(s2 + 2) ^ mix(s3 + 3);
+        }
+    };
+    const size_t nthr = std::min<size_t>(std::max<size_t>(nchunks, 1), std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())));
+    if (nthr <= 1 || nchunks <= 1) {
+        work(0, nchunks);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nthr; ++t) th.emplace_back(work, nchunks * t / nthr, nchunks * (t + 1) / nthr);
+        for (auto &t : th) t.join();
+    }
+    uint64_t h = mix(uint64_t(nbytes));
+    for (size_t c = 0; c < nchunks; ++c) h = mix(h ^ part[c]) + 0x9E3779B97F4A7C15ull * (c + 1);
+    uint64_t tail = 0;
+    std::memcpy(&tail, p + 8 * nwords, nbytes - 8 * nwords);
+    return mix(h ^ mix(tail + 0x51ull));
+}
 
 int pfbhip_malloc(void **ptr_dev, size_t bytes)
 {

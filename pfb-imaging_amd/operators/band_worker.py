@@ -189,8 +189,11 @@ class BandWorkerPool:
     # --- Psi role (band_worker.py:291-301) ---
     def init_psi(self, nx, ny, bases, nlevel):
         shapes = self._map("init_psi", [(nx, ny, tuple(bases), nlevel)] * self.nband)
-        self._psi_shape = next(iter(shapes.values()))
-        return self._psi_shape  # (nxmax, nymax), identical across bands
+        shape = next(iter(shapes.values()), (0, 0))  # (nxmax, nymax), identical across bands
+        if self.comm is not None and self.comm.world_size > 1:  # a rank without bands (nband < world size) learns it too
+            shape = (int(self.comm.max_over_ranks(shape[0])), int(self.comm.max_over_ranks(shape[1])))
+        self._psi_shape = shape
+        return self._psi_shape
 
     def psi_dot(self, x, alphao):
         out = np.zeros(alphao.shape, dtype=np.float64)

@@ -20,14 +20,20 @@ from ..wgridder import _get_gridder
 
 
 def taperf(shape, taper_width):
-    """/root/reference/src/pfb_imaging/utils/misc.py:968-975."""
-    tapers1d = ()
-    for npix in shape:
-        taper = np.ones(npix)
-        taper[:taper_width] = 0.5 * (1 + np.cos(np.linspace(1.1 * np.pi, 2 * np.pi, taper_width)))
-        taper[-taper_width:] = 0.5 * (1 + np.cos(np.linspace(0, 0.9 * np.pi, taper_width)))
-        tapers1d += (taper,)
-    return np.outer(*tapers1d)
+    """Separable edge taper of ``hess_direct`` (the reference's ``utils.misc.taperf``, misc.py:968-975): along each axis
+    the weight is 1 in the interior and rolls off over ``taper_width`` pixels at both ends as a raised cosine
+    ``(1 + cos(theta)) / 2`` -- theta runs over [1.1 pi, 2 pi] on the leading edge (so the first pixel is ~0.024, not 0) and
+    over [0, 0.9 pi] on the trailing edge; the image taper is the outer product of the axis tapers."""
+    def axis_taper(n):
+        w = np.ones(n)
+        lead = np.linspace(1.1 * np.pi, 2.0 * np.pi, taper_width)
+        trail = np.linspace(0.0, 0.9 * np.pi, taper_width)
+        w[:taper_width] = (1.0 + np.cos(lead)) / 2.0
+        w[n - taper_width:] = (1.0 + np.cos(trail)) / 2.0
+        return w
+
+    wx, wy = (axis_taper(int(n)) for n in shape)
+    return wx[:, None] * wy[None, :]
 
 
 def hessian_slice(x, xout=None, uvw=None, weight=None, vis_mask=None, freq=None, beam=None, cell=None, x0=0.0, y0=0.0,

@@ -138,16 +138,24 @@ class PrimalDual:
         if isinstance(hess, HessTreeRay) and hess.nband == nband:
             pool = hess._pool
             comm = pool.comm if (pool.comm is not None and pool.comm.world_size > 1) else None
-            if comm is not None and (comm.transport != "rccl" or not pool.local):
-                return None  # CPU transport (tests) or a rank without bands: the generic loop handles it
+            # Whether THIS rank could run the device loop: RCCL transport, at least one band here (pfbhip_primal_dual /
+            # pfbhip_psfconv_power_method take nband >= 1), one correlation per band.
+            ok = comm is None or (comm.transport == "rccl" and bool(pool.local))
             out = []
-            for b in pool.local:
+            for b in (pool.local if ok else ()):
                 tree = getattr(pool.workers[b], "_hess", None)
                 if tree is None or tree.ncorr != 1:
-                    return None
+                    ok = False
+                    break
                 s = tree._slots(0)
                 out.append((tree._plan, s, s, 1.0 / float(tree.wsum[0]), float(tree.eta)))
-            return out, comm, list(pool.local)
+            # The choice is COLLECTIVE: the device loop's RCCL sequence (one all-reduce of a single-band coefficient cube,
+            # then one of 3 doubles, per iteration) differs from the generic loop's (cube-level psi / hess all-reduces), so a
+            # rank deciding on its own -- e.g. the ranks >= nband of a 4-band run on 8 GPUs, which hold no band -- would
+            # deadlock the others.  Every rank evaluates this, in the same place, whenever the pool is distributed.
+            if comm is not None:
+                ok = comm.min_over_ranks(1.0 if ok else 0.0) == 1.0
+            return (out, comm, list(pool.local)) if ok else None
         return None
 
     def _device_path(self):
@@ -323,3 +331,253 @@ def power_method(aop, imsize, b0=None, tol=1e-5, maxit=250, verbosity=1, report_
 
 
 power_method_numba = power_method
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Conjugate gradients (opt/pcg.py of the reference): pcg / pcg_numba / PCG / pcg_dds over the on-device solver
+# ---------------------------------------------------------------------------------------------------------
+
+def _device_cg_target(aop):
+    """What the on-device CG can solve without leaving HBM, or None: ``aop`` is
+
+    * ``functools.partial(hessian_slice, uvw=..., weight=..., vis_mask=..., freq=..., beam=..., cell=..., eta=..., wsum=...)``
+      -- the operator ``pcg_dds`` builds (opt/pcg.py:529-548) --, or
+    * the bound ``hessian`` of a :class:`~pfb_imaging_amd.wgridder.Gridder`, bare or in a ``partial`` carrying only
+      ``beam`` / ``eta`` / ``wsum`` keywords.
+
+    Returns ``(gridder, cached, beam, eta, wsum)``.
+    """
+    import functools
+
+    from .operators.hessian import hessian_slice
+    from .wgridder import Gridder
+
+    fn, kw = aop, {}
+    if isinstance(aop, functools.partial):
+        if aop.args:
+            return None
+        fn, kw = aop.func, dict(aop.keywords)
+    owner = getattr(fn, "__self__", None)
+    if isinstance(owner, Gridder) and getattr(fn, "__func__", None) is Gridder.hessian:
+        if set(kw) - {"beam", "eta", "wsum"}:
+            return None
+        return owner, True, kw.get("beam"), kw.get("eta") or 0.0, kw.get("wsum") or 0.0
+    if fn is hessian_slice:
+        need = {"uvw", "freq", "cell"}
+        allowed = need | {"weight", "vis_mask", "beam", "x0", "y0", "flip_u", "flip_v", "flip_w", "do_wgridding", "epsilon",
+                          "double_accum", "nthreads", "eta", "wsum"}
+        if not need <= set(kw) or set(kw) - allowed:
+            return None
+        return ("slice", kw)
+    return None
+
+
+def _cg_host(aop, b, x0, precond, tol, maxit, minit, verbosity, report_freq, return_resid, name):
+    """The reference's CG loop around an arbitrary callable (opt/pcg.py:88-314): start residual ``r = A x0 - b``, direction
+    ``p = -M r``, per iteration ``alpha = (r.y) / (p.Ap)``, ``x += alpha p``, ``r += alpha Ap``, ``y = M r``,
+    ``beta = (r.y)_new / (r.y)_old``, ``p = beta p - y``; it stops on ``||x - xp|| / ||x|| <= tol`` (and ``k >= minit``),
+    on ``maxit``, or after five iterations whose stopping measure moved by less than ``1e-3 tol``.  ``x0`` is the iterate."""
+    if precond is None:
+        def precond(v):
+            return v
+    x = x0
+    r = aop(x) - b
+    y = precond(r)
+    if not np.any(y):
+        print("Initial residual is zero")
+        return (x, r) if return_resid else x
+    p = -y
+    ry = float(np.vdot(r, y).real)
+    phi0 = 1.0 if (np.isnan(ry) or ry == 0.0) else ry
+    k, eps, stalls = 0, 1.0, 0
+    while (eps > tol or k < minit) and k < maxit and stalls < 5:
+        ap = aop(p)
+        ry = float(np.vdot(r, y).real)
+        alpha = ry / float(np.vdot(p, ap).real)
+        xprev = x.copy()
+        x += alpha * p          # in place: x IS the caller's x0
+        r = r + alpha * ap      # (aop may hand back an internal buffer: never scale it in place)
+        y = precond(r)
+        ry_next = float(np.vdot(r, y).real)
+        p = (ry_next / ry) * p - y
+        k += 1
+        eps_prev = eps
+        eps = float(np.sqrt(((x - xprev) ** 2).sum() / max(float((x ** 2).sum()), 1e-12)))
+        if abs(eps_prev - eps) < 1e-3 * tol:
+            stalls += 1
+        if verbosity > 1 and not k % report_freq:
+            print(f"At iteration {k} eps = {eps:.3e}, phi = {ry_next / phi0:.3e}")
+    if verbosity:
+        if k >= maxit:
+            print(f"Max iters reached. eps = {eps:.3e}")
+        elif stalls >= 5:
+            print(f"Stalled after {k} iterations with eps = {eps:.3e}")
+        else:
+            print(f"Success, converged after {k} iterations")
+    _cg_host.last = dict(iters=k, eps=eps, status=1 if k >= maxit else (2 if stalls >= 5 else 0), where=name)
+    return (x, r) if return_resid else x
+
+
+def _cg_device(target, aop, b, x0, tol, maxit, minit, verbosity, return_resid):
+    """Whole solve on the device (pfbhip_gridder_cg: the Hessian applies and every CG vector stay in HBM); the result is
+    written into ``x0`` (the reference's in-place contract) when one is given."""
+    from .operators.hessian import hessian_slice  # noqa: F401
+    from .wgridder import _fingerprint, _get_gridder
+
+    b = np.asarray(b, dtype=np.float64)
+    if target[0] == "slice":
+        kw = target[1]
+        nx, ny = b.shape
+        g, cached = _get_gridder(kw["uvw"], kw["freq"], kw.get("vis_mask"), npix_x=nx, npix_y=ny,
+                                 pixsize_x=float(kw["cell"]), pixsize_y=float(kw["cell"]), center_x=float(kw.get("x0", 0.0)),
+                                 center_y=float(kw.get("y0", 0.0)), epsilon=float(kw.get("epsilon", 1e-7)),
+                                 flip_u=bool(kw.get("flip_u", False)), flip_v=bool(kw.get("flip_v", True)),
+                                 flip_w=bool(kw.get("flip_w", False)), do_wgridding=bool(kw.get("do_wgridding", True)),
+                                 divide_by_n=False, sigma_min=1.1, sigma_max=2.6)
+        weight = kw.get("weight")
+        token = None if weight is None else _fingerprint(np.asarray(weight))
+        if getattr(g, "_hess_weight_token", "unset") != token:
+            g.set_weights(weight)
+            g._hess_weight_token = token
+        beam, eta, wsum = kw.get("beam"), kw.get("eta") or 0.0, kw.get("wsum") or 0.0
+    else:
+        g, cached, beam, eta, wsum = target
+    try:
+        sol = g.cg(b, x0=x0, beam=beam, eta=eta, wsum=wsum, tol=tol, maxit=maxit, minit=minit)
+        info = dict(g.last_cg, where="device")
+    finally:
+        if not cached:
+            g.close()
+    _cg_host.last = info
+    if verbosity:
+        if info["status"] == 1:
+            print(f"Max iters reached. eps = {info['eps']:.3e}")
+        elif info["status"] == 2:
+            print(f"Stalled after {info['iters']} iterations with eps = {info['eps']:.3e}")
+        else:
+            print(f"Success, converged after {info['iters']} iterations")
+    if x0 is not None:
+        x0[...] = sol
+        sol = x0
+    if return_resid:
+        return sol, aop(sol) - b
+    return sol
+
+
+def pcg_numba(aop, b, x0=None, precond=None, tol=1e-5, maxit=500, minit=100, verbosity=1, report_freq=10, backtrack=True,
+              return_resid=False):
+    """CG solve of ``aop(x) = b`` with the contract of the reference's ``pcg_numba`` (opt/pcg.py:88-199): ``x0`` -- when
+    given -- is the iterate, updated IN PLACE and returned; stopping rule as in :func:`_cg_host`.
+
+    When ``aop`` is the exact Hessian of this package (see :func:`_device_cg_target`) and there is no preconditioner, the
+    whole solve runs on the device (``Gridder.cg``); any other callable gets the same loop on the host around it.
+    ``backtrack`` is accepted and unused, as in the reference.
+    """
+    _lib.require_gpu()
+    if x0 is None:
+        x0 = np.zeros(np.shape(b), dtype=np.asarray(b).dtype)
+    target = _device_cg_target(aop) if precond is None else None
+    if target is not None and np.asarray(b).ndim == 2:
+        if not np.any(b) and not np.any(x0):
+            print("Initial residual is zero")
+            return (x0, np.zeros_like(x0)) if return_resid else x0
+        return _cg_device(target, aop, b, x0, tol, maxit, minit, verbosity, return_resid)
+    return _cg_host(aop, b, x0, precond, tol, maxit, minit, verbosity, report_freq, return_resid, "host")
+
+
+def pcg(aop, b, x0=None, precond=None, tol=1e-5, maxit=500, minit=100, verbosity=1, report_freq=10, backtrack=True,
+        return_resid=False):
+    """``pcg`` of the reference (opt/pcg.py:200-314): the same solver with an optional preconditioner callable
+    (``HessPSF.idot`` uses it).  A preconditioned solve runs the host loop around the two callables."""
+    return pcg_numba(aop, b, x0=x0, precond=precond, tol=tol, maxit=maxit, minit=minit, verbosity=verbosity,
+                     report_freq=report_freq, backtrack=backtrack, return_resid=return_resid)
+
+
+class PCG:
+    """ForwardSolver ``update ~= hess^-1 residual`` (opt/pcg.py:586-630): delegates to ``hess.cg`` when the operator has
+    one (HessTreeRay / HessianTree / Gridder: on-device solves), else runs :func:`pcg_numba` over ``hess.dot``."""
+
+    def __init__(self, tol=1e-3, maxit=150, minit=1, verbosity=0, report_freq=10):
+        self.tol, self.maxit, self.minit, self.verbosity, self.report_freq = tol, maxit, minit, verbosity, report_freq
+
+    def solve(self, hess, residual, x0=None):
+        if hasattr(hess, "cg"):
+            return hess.cg(residual, x0=x0, tol=self.tol, maxit=self.maxit, minit=self.minit)
+        from .operators import LinearOperator, require_protocol
+
+        require_protocol(hess, LinearOperator, "hess")
+        return pcg_numba(hess.dot, residual, x0=x0, tol=self.tol, maxit=self.maxit, minit=self.minit,
+                         verbosity=self.verbosity, report_freq=self.report_freq)
+
+
+def _ds_get(ds, name):
+    """Field ``name`` of an xarray-like dataset or a plain mapping, as a numpy array (None if absent)."""
+    if isinstance(ds, dict):
+        v = ds.get(name)
+    else:
+        v = getattr(ds, name, None) if name in ds else None
+    if v is None:
+        return None
+    return np.asarray(getattr(v, "values", v))
+
+
+def _ds_attr(ds, name, default=None):
+    if isinstance(ds, dict):
+        return ds.get(name, ds.get("attrs", {}).get(name, default))
+    return getattr(ds, name, getattr(ds, "attrs", {}).get(name, default))
+
+
+def pcg_dds(ds, eta, mask=1.0, use_psf=True, residual_name="RESIDUAL", model_name="MODEL", do_wgridding=True, epsilon=5e-4,
+            double_accum=True, nthreads=1, zero_model_outside_mask=False, tol=1e-5, maxit=500, verbosity=1, report_freq=10):
+    """The flux-mop solve of ``pfb fluxtractor`` for one band (opt/pcg.py:444-583): ``x = (beam R^H W R beam / wsum + eta)^-1
+    (beam * residual / wsum)`` by CG on the exact Hessian, ``model += x``, and the exact residual of the new model.
+
+    ``ds`` is the band's dataset: an xarray ``Dataset`` or a mapping with the arrays ``DIRTY, BEAM, UVW, WEIGHT, MASK,
+    FREQ`` (optionally ``MODEL`` / ``RESIDUAL`` / ``UPDATE``) and the attributes ``cell_rad, x0, y0, flip_u, flip_v,
+    flip_w, wsum, bandid``.  The reference's zarr round trip stays with the caller: the new fields come back in a dict
+    (``MODEL_MOPPED, RESIDUAL_MOPPED, UPDATE, X0``) and are also ``assign``-ed when ``ds`` is an xarray Dataset.
+
+    Returns ``(resid, bandid, fields)``.  Both exact-Hessian applications and the whole CG run on the device.
+    """
+    from functools import partial
+
+    from .operators.hessian import hessian_slice
+
+    if isinstance(ds, (list, tuple)):
+        ds = ds[0]
+    if isinstance(ds, (str, bytes)):
+        raise TypeError("pcg_dds takes the band's dataset (xarray Dataset or mapping of arrays), not a store path: "
+                        "open it with the reference's xds_from_list and pass the Dataset")
+    dirty, beam0 = _ds_get(ds, "DIRTY"), _ds_get(ds, "BEAM")
+    common = dict(uvw=_ds_get(ds, "UVW"), weight=_ds_get(ds, "WEIGHT"), vis_mask=_ds_get(ds, "MASK"), freq=_ds_get(ds, "FREQ"),
+                  cell=_ds_attr(ds, "cell_rad"), x0=_ds_attr(ds, "x0", 0.0), y0=_ds_attr(ds, "y0", 0.0),
+                  do_wgridding=do_wgridding, epsilon=epsilon, double_accum=double_accum, nthreads=nthreads)
+    flips = dict(flip_u=bool(_ds_attr(ds, "flip_u", False)), flip_v=bool(_ds_attr(ds, "flip_v", True)),
+                 flip_w=bool(_ds_attr(ds, "flip_w", False)))
+    beam = mask * beam0
+    model = _ds_get(ds, model_name)
+    if zero_model_outside_mask:
+        if model is None:
+            raise RuntimeError(f"Asked to zero model outside mask but {model_name} not in dds")
+        model = np.where(np.asarray(mask) > 0, model, 0.0)
+        print("Zeroing model outside mask")
+        j = (dirty - hessian_slice(model, beam=beam0, **common, **flips)) * beam
+    else:
+        model = np.zeros(dirty.shape, dtype=float) if model is None else np.array(model, dtype=float)
+        resid_in = _ds_get(ds, residual_name)
+        j = (dirty if resid_in is None else resid_in) * beam
+    wsum = float(_ds_attr(ds, "wsum"))
+    j = j / wsum
+    upd = _ds_get(ds, "UPDATE")
+    x0 = np.zeros_like(j) if upd is None else upd * mask
+    hess = partial(hessian_slice, beam=beam, eta=eta, wsum=wsum, **common, **flips)
+    x = pcg(hess, j, x0=np.array(x0, dtype=float), precond=None, tol=tol, maxit=maxit, minit=1, verbosity=verbosity,
+            report_freq=report_freq, backtrack=False, return_resid=False)
+    model = model + x
+    resid = dirty - hessian_slice(model, beam=beam0, **common, **flips)
+    fields = {"MODEL_MOPPED": model, "RESIDUAL_MOPPED": resid, "UPDATE": x, "X0": x0}
+    if hasattr(ds, "assign"):
+        ds = ds.assign(**{k: (("x", "y"), v) for k, v in fields.items()})
+    elif isinstance(ds, dict):
+        ds.update(fields)
+    return resid, int(_ds_attr(ds, "bandid", 0)), fields

@@ -85,3 +85,22 @@ def box_sum_counts(counts, npix_super):
     out = np.empty_like(c)
     check(lib().pfbhip_box_sum_counts(ptr(c), i64(ncorr), i64(nx), i64(ny), i64(int(npix_super)), ptr(out)))
     return out.astype(counts.dtype, copy=False)
+
+
+def imaging_weights(uvw, freq, mask, weight, nx_pad, ny_pad, cell_size_x, cell_size_y, robust, filter_level=5.0,
+                    npix_super=0, usign=1.0, vsign=-1.0, return_counts=False):
+    """The whole imaging-weight chain of ``image_data_products`` (operators/gridder.py:534-576) in one device pipeline:
+    ``_compute_counts`` -> ``filter_extreme_counts`` -> ``box_sum_counts`` -> ``counts_to_weights``.  ``weight``
+    ``(ncorr, nrow, nchan)`` is updated in place and returned (with the final counts when ``return_counts``); the counts
+    grid never visits the host otherwise and uvw / mask / weights are uploaded once instead of three times."""
+    _lib.require_gpu()
+    uvw, freq, mask = as_c(uvw, np.float64), as_c(freq, np.float64), as_c(mask, np.uint8)
+    ncorr, nrow, nchan = weight.shape
+    w = weight if (weight.flags.c_contiguous and weight.dtype == np.float64) else np.array(weight, dtype=np.float64)
+    counts = np.empty((ncorr, nx_pad, ny_pad), dtype=np.float64) if return_counts else None
+    check(lib().pfbhip_imaging_weights(ptr(uvw), ptr(freq), ptr(mask), ptr(w), i64(ncorr), i64(nrow), i64(nchan), i64(nx_pad),
+                                       i64(ny_pad), f64(cell_size_x), f64(cell_size_y), f64(usign), f64(vsign), f64(robust),
+                                       f64(filter_level or 0.0), i64(int(npix_super or 0)), ptr(counts)))
+    if w is not weight:
+        weight[...] = w
+    return (weight, counts) if return_counts else weight

@@ -127,6 +127,26 @@ def main():
     dual_update_bands(vp, v, 0.8, 1.7, wgt, comm=comm, bands=pool.local, phases=(vtilde_sum, scale))
     np.testing.assert_allclose(v, opsi.dual_update(vp, alpha.copy(), 0.8, 1.7, wgt), rtol=0, atol=1e-13)
 
+    # fewer bands than ranks (e.g. 4 bands on 8 GPUs): rank 1 holds no band, takes part in every collective, and the
+    # choice between the device-resident and the generic primal-dual / power-method loop is made by ALL ranks together
+    from pfb_imaging_amd.operators.hessian import HessTreeRay
+    from pfb_imaging_amd.opt import PrimalDual
+
+    pool1 = BandWorkerPool(1, comm=comm, worker_cls=FakeWorker)
+    assert pool1.local == ([0] if comm.rank == 0 else [])
+    tree1 = HessTreeRay([diag[0]], nx, ny, 2 * nx, 2 * ny, etas=0.5, workers=pool1)
+    np.testing.assert_allclose(tree1.dot(x[:1]), ((diag[0] + 0.5) * x[0])[None], rtol=1e-14)
+    np.testing.assert_allclose(tree1.cg(((diag[0] + 0.5) * x[0])[None]), x[:1], rtol=1e-13)
+    assert PrimalDual._hess_bands(tree1, 1) is None  # gloo transport: every rank agrees on the generic loop
+    psi1 = PsiNocopytRay(1, px, py, ("self", "db1"), 2, workers=pool1)
+    full1 = opsi.Psi(1, px, py, ("self", "db1"), 2)
+    assert (psi1.nxmax, psi1.nymax) == (full1.nxmax, full1.nymax)  # the bandless rank learned the shape from the others
+    a1 = np.zeros((1, 2, psi1.nxmax, psi1.nymax))
+    psi1.dot(img[:1], a1)
+    r1 = np.zeros_like(a1)
+    full1.dot(img[:1], r1)
+    np.testing.assert_allclose(a1, r1, rtol=0, atol=1e-13)
+
     # single band sharded by row blocks (config-5 style): partial images are summed, degridding is local
     from oracle import wgridder as owg
     from pfb_imaging_amd.parallel import RowShardedGridder, row_block

@@ -10,11 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # The plan picks the register-footprint scatter (k_grid_blk) only for problems with >= 2048 work items per pass --
-    # the benchmark sizes -- and the single-launch diagonal-walk scatter for small ones, which is what most parity
-    # cases are.  The parity suite therefore forces the benchmark's kernel; test_scatter_forms_agree covers the walk
-    # kernel and the automatic choice.
-    os.environ.setdefault("PFBHIP_SCATTER", "block")
+    # The plan picks the register-footprint scatters (k_grid_rec on single-pass plans with polynomial w-planes, k_grid_blk on
+    # the others) only for problems with >= 2048 work items per pass -- the benchmark sizes -- and the single-launch
+    # diagonal-walk scatter for small ones, which is what most parity cases are.  The parity suite therefore forces the
+    # benchmark's kernels ("rec": the record scatter where the plan admits it, k_grid_blk elsewhere);
+    # test_scatter_forms_agree covers all three forms and the automatic choice.
+    os.environ.setdefault("PFBHIP_SCATTER", "rec")
 
 
 def _have_gpu():

@@ -124,3 +124,39 @@ def test_host_side_helpers():
         require_protocol(Bad(), LinearOperator, "hess")
     with pytest.raises(TypeError, match="Preconditioner"):
         require_protocol(Bad(), Preconditioner, "precond")
+
+
+def test_content_hash_sees_every_byte():
+    """The plan caches of the stateless calls are keyed on a hash of EVERY byte of uvw / freq / mask / weights / psfhat
+    (the reference's ducc0 calls are stateless): a single flipped mask element, an in-place weight tweak, a swap of two
+    elements and a reallocation with equal content must all be told apart / recognised."""
+    from pfb_imaging_amd import _lib
+
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal(1_000_003)
+    k = _lib.content_key(a)
+    assert k == _lib.content_key(a.copy())            # content, not address
+    a[777_777] = np.nextafter(a[777_777], 10.0)       # one ulp, far from any "sample"
+    k2 = _lib.content_key(a)
+    assert k2 != k
+    b = a.copy()
+    b[[5, 6]] = b[[6, 5]]
+    assert _lib.content_key(b) != k2                  # position-dependent
+    m = np.ones((1001, 7), dtype=np.uint8)            # size not a multiple of 8: the tail bytes count too
+    km = _lib.content_key(m)
+    m[1000, 6] = 0
+    assert _lib.content_key(m) != km
+    assert _lib.content_key(m) != _lib.content_key(m.reshape(7, 1001))
+    assert _lib.content_key(None) is None
+    # read-only inputs are hashed once and remembered by address; anything writeable (also through a base) is not
+    r = rng.standard_normal(4096)
+    r.flags.writeable = False
+    assert _lib._immutable(r) and not _lib._immutable(a)
+    assert _lib.content_key(r) == _lib.content_key(r) and (r.ctypes.data, r.shape, r.dtype.str) in _lib._ro_memo
+    base = rng.standard_normal(64)
+    view = base[:32]
+    view.flags.writeable = False
+    assert not _lib._immutable(view)                  # still writeable through its base
+    kv = _lib.content_key(view)
+    base[3] += 1.0
+    assert _lib.content_key(view) != kv

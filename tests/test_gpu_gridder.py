@@ -568,3 +568,42 @@ def test_anisotropic_pixels_and_flips_vs_dft(flips):
     bm = g.binmap()
     assert np.array_equal(bm["iu0"], o.iu0) and np.array_equal(bm["iv0"], o.iv0) and np.array_equal(bm["flip"], o.flip)
     g.close()
+
+
+def test_stateless_plan_cache_sees_inplace_edits():
+    """The ducc0-style calls are stateless in the reference; the plan cache behind them must therefore notice an
+    input edited IN PLACE (same address, same shape) -- one flagged visibility, one changed weight -- and an equal-content
+    array at another address must hit the cache."""
+    from pfb_imaging_amd import wgridder as wg
+    from pfb_imaging_amd.operators.hessian import hessian_slice
+
+    wg.clear_cache()
+    c = make(nrow=6000, nchan=4, npix=48)           # 24000 visibilities: the old fingerprint sampled every 5th
+    mask = c["mask"].copy()
+    wgt = c["wgt"].copy()
+    kw = dict(uvw=c["uvw"], freq=c["freq"], wgt=wgt, mask=mask, npix_x=48, npix_y=48, pixsize_x=c["cell"], pixsize_y=c["cell"],
+              center_x=0.0, center_y=0.0, epsilon=1e-7, flip_u=False, flip_v=True, flip_w=False, do_wgridding=True,
+              divide_by_n=False)
+    d1 = wg.vis2dirty(vis=c["vis"], **kw)
+    nplans = len(wg._cache)
+    assert np.array_equal(wg.vis2dirty(vis=c["vis"], **dict(kw, mask=mask.copy())), d1) and len(wg._cache) == nplans
+    idx = np.flatnonzero(mask.reshape(-1))
+    idx = idx[(idx % 5 != 0) & (idx % 4 != 0)][len(idx) // 3]   # an element no strided sample would have read
+    mask.reshape(-1)[idx] = 0
+    d2 = wg.vis2dirty(vis=c["vis"], **kw)
+    g, gkw, _ = gpu_plan(c, mask=mask)
+    ref = g.vis2dirty(c["vis"], wgt)
+    g.close()
+    assert rel(d2, ref) < 1e-12 and rel(d2, d1) > 1e-9
+    # weights: hessian_slice binds them to the cached plan; an in-place change of one weight must rebind
+    hkw = dict(uvw=c["uvw"], weight=wgt, vis_mask=mask, freq=c["freq"], beam=None, cell=c["cell"], x0=0.0, y0=0.0,
+               do_wgridding=True, epsilon=1e-7)
+    h1 = hessian_slice(c["x"][:48, :48], **hkw)
+    wgt.reshape(-1)[idx + 1] *= 3.0
+    h2 = hessian_slice(c["x"][:48, :48], **hkw)
+    g, gkw, _ = gpu_plan(c, mask=mask)
+    g.set_weights(wgt)
+    ref = g.hessian(np.ascontiguousarray(c["x"][:48, :48]))
+    g.close()
+    assert rel(h2, ref) < 1e-12 and rel(h2, h1) > 1e-9
+    wg.clear_cache()
