@@ -586,7 +586,8 @@ def test_stateless_plan_cache_sees_inplace_edits():
               divide_by_n=False)
     d1 = wg.vis2dirty(vis=c["vis"], **kw)
     nplans = len(wg._cache)
-    assert np.array_equal(wg.vis2dirty(vis=c["vis"], **dict(kw, mask=mask.copy())), d1) and len(wg._cache) == nplans
+    # (two runs agree to rounding, not bit for bit: the scatter adds into its tile with LDS atomics)
+    assert rel(wg.vis2dirty(vis=c["vis"], **dict(kw, mask=mask.copy())), d1) < 1e-13 and len(wg._cache) == nplans
     idx = np.flatnonzero(mask.reshape(-1))
     idx = idx[(idx % 5 != 0) & (idx % 4 != 0)][len(idx) // 3]   # an element no strided sample would have read
     mask.reshape(-1)[idx] = 0
