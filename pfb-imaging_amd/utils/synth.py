@@ -16,7 +16,9 @@ CONFIGS = {
     "C1": (50_000, 2, 1024, 1e-3),
     "C2": (1_250_000, 8, 8192, 1e-3),
     "C4": (1_250_000, 8, 4096, 1e-3),
-    "C5": (12_500_000, 8, 16384, 0.3),
+    # antenna z-scale 1.4: with the C5 cell (16384^2 pixels over the full field) the plan then needs 64 ES-kernel w-planes
+    # at epsilon 1e-7 (tools/calib_c5.py on the GPU box: planes = 15 + 35 zscale) -- the count BASELINE.json names
+    "C5": (12_500_000, 8, 16384, 1.4),
 }
 
 

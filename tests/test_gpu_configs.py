@@ -1,0 +1,149 @@
+"""Full-size parity at the BASELINE configurations other than C2 (C2 / C3: tests/test_gpu_fullsize.py), through the C-ABI:
+
+  C1  1 band, 1e5 visibilities -> 1024^2 image: whole-image comparison with the algorithm restatement (oracle.wgridder,
+      run with the GPU plan's parameters) and direct-DFT spot checks.
+  C4  SARA primal-dual: 4 bands, 4096^2, dictionary self+db1+db2+db3 with 3 levels: Psi perfect reconstruction and
+      adjointness at size; the device-resident PD loop equals the host loop for 3 iterations.
+  C5  wide-field w-stacking: 1e8 visibilities, 16384^2 image, 64 ES-kernel w-planes: direct-DFT spot checks and
+      adjointness.
+
+Tolerances: epsilon (1e-7) relative L2 against the DFT; 1e-10 against the restatement and for algebraic identities.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dft  # noqa: E402
+from oracle import wgridder as owg  # noqa: E402
+from pfb_imaging_amd.utils import synth  # noqa: E402
+
+EPS = 1e-7
+KW = dict(center_x=0.0, center_y=0.0, epsilon=EPS, flip_u=False, flip_v=True, flip_w=False, do_wgridding=True, divide_by_n=False,
+          sigma_min=1.1, sigma_max=3.0)
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def test_c1_whole_image_vs_restatement_and_dft(monkeypatch):
+    """BASELINE config C1 (the reference's own CPU-runnable case) with the kernels the plan picks by itself (the
+    single-launch walk scatter at this size) and with the benchmark kernels forced."""
+    from pfb_imaging_amd.wgridder import Gridder
+
+    c = synth.make_config("C1", band=0)
+    nx = c["nx"]
+    rng = np.random.default_rng(0)
+    ix, iy = rng.integers(0, nx, 40), rng.integers(0, nx, 40)
+    dref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], c["mask"], nx, nx, c["cell"], c["cell"], 0.0, 0.0, False, True,
+                             False, True, False, pixels=(ix, iy))
+    rows, chans = rng.integers(0, c["uvw"].shape[0], 3000), rng.integers(0, 2, 3000)
+    keep = c["mask"][rows, chans] != 0
+    rows, chans = rows[keep], chans[keep]
+    x = np.zeros((nx, nx))
+    x[rng.integers(0, nx, 300), rng.integers(0, nx, 300)] = rng.standard_normal(300)
+    vref = dft.dft_dirty2vis(c["uvw"], c["freq"], x, c["cell"], c["cell"], 0.0, 0.0, False, True, False, True, False, rows=rows,
+                             chans=chans)
+    images = {}
+    for mode in ("auto", "rec"):
+        if mode == "auto":
+            monkeypatch.delenv("PFBHIP_SCATTER", raising=False)
+        else:
+            monkeypatch.setenv("PFBHIP_SCATTER", mode)
+        g = Gridder(c["uvw"], c["freq"], c["mask"], npix_x=nx, npix_y=nx, pixsize_x=c["cell"], pixsize_y=c["cell"], **KW)
+        assert g.info["scatter_mode"] == (0 if mode == "auto" else 2)
+        o = owg.Plan(c["uvw"], c["freq"], c["mask"], nx, nx, c["cell"], c["cell"], 0.0, 0.0, EPS, False, True, False, True, False,
+                     params=g.oracle_params())
+        dirty = g.vis2dirty(c["vis"], c["wgt"])
+        assert rel(dirty, o.vis2dirty(c["vis"], c["wgt"])) < 1e-10
+        assert rel(dirty[ix, iy], dref) < EPS
+        vis = g.dirty2vis(x)
+        assert rel(vis, o.dirty2vis(x)) < 1e-10 and rel(vis[rows, chans], vref) < EPS
+        g.set_weights(c["wgt"])
+        assert rel(g.hessian(c["x"]), o.vis2dirty(o.dirty2vis(c["x"]), c["wgt"])) < 1e-10
+        images[mode] = dirty
+        g.close()
+    assert rel(images["auto"], images["rec"]) < 1e-10
+
+
+def test_c4_dictionary_and_primal_dual_at_size():
+    """BASELINE config C4: 4 bands, 4096^2 images, dictionary (self, db1, db2, db3) with 3 levels (core/deconv.py:32-33),
+    PSF-approximate Hessian on the 2x padded grid."""
+    from pfb_imaging_amd import prox
+    from pfb_imaging_amd.operators.hessian import HessPSF
+    from pfb_imaging_amd.operators.psi import PsiNocopyt
+    from pfb_imaging_amd.opt import L21, PrimalDual, PsfGrad
+
+    nband, n, npsf = 4, 4096, 8192
+    bases, nlevel = ("self", "db1", "db2", "db3"), 3
+    rng = np.random.default_rng(4)
+    psi = PsiNocopyt(nband, n, n, bases, nlevel, 1)
+    x = rng.standard_normal((nband, n, n))
+    alpha = np.zeros((nband, len(bases), psi.nxmax, psi.nymax))
+    psi.dot(x, alpha)
+    back = np.zeros_like(x)
+    psi.hdot(alpha, back)
+    assert rel(back, len(bases) * x) < 1e-12                       # Psi Psi^H = nbasis I (orthogonal wavelets + identity)
+    beta = rng.standard_normal(alpha.shape)
+    xb = np.zeros_like(x)
+    psi.hdot(beta, xb)
+    lhs, rhs = np.vdot(alpha, beta), np.vdot(x, xb)
+    assert abs(lhs - rhs) <= 1e-11 * abs(lhs)                      # <Psi^H x, beta> == <x, Psi beta>
+    # device-resident primal-dual loop == the reference's loop (GPU dictionary / dual update, host vector steps), 3 iterations
+    psfhat = np.empty((nband, npsf, npsf // 2 + 1))
+    ky = np.fft.fftfreq(npsf)[:, None] ** 2
+    kx = np.fft.rfftfreq(npsf)[None, :] ** 2
+    for b in range(nband):                                          # a smooth, band-dependent |PSFHAT| (a Gaussian beam's transfer function)
+        psfhat[b] = np.exp(-(ky + kx) * (3.0e4 + 1.0e4 * b))
+    eta = np.full(nband, 0.05)
+    hess = HessPSF(n, n, psfhat, beam=None, eta=eta)
+    model = np.abs(rng.standard_normal((nband, n, n))) * (rng.random((nband, n, n)) > 0.99)
+    xtilde = model + 0.1 * rng.standard_normal(model.shape)
+    reg = L21(psi, bases, nu=np.sqrt(len(bases)))
+    sols = []
+    for device in (True, False):
+        pd = PrimalDual(tol=0.0, maxit=3, verbosity=0, gamma=1.0, primal_prox=prox.positivity_prox(1))
+        pd.setup(reg, 1.0 + eta.max())
+        grad = PsfGrad(hess, xtilde, 1.0)
+        pd.set_grad(grad if device else (lambda z: grad(z)))
+        assert (pd._device_path() is not None) == device
+        sols.append(pd.solve(model.copy(), 0.01))
+        assert pd.last["iters"] == 2                                # (0-based index of the last iteration)
+    assert rel(sols[0], sols[1]) < 1e-10
+
+
+def test_c5_wide_field_64_planes_spot_checks():
+    """BASELINE config C5: 1e8 visibilities, 16384^2 image; the synthetic array's z-scale is chosen so that the plan needs
+    64 ES-kernel w-planes (tools/calib_c5.py)."""
+    from pfb_imaging_amd.wgridder import Gridder
+
+    c = synth.make_config("C5", band=0)
+    nx = c["nx"]
+    g = Gridder(c["uvw"], c["freq"], c["mask"], npix_x=nx, npix_y=nx, pixsize_x=c["cell"], pixsize_y=c["cell"], **KW)
+    assert g.info["wmode"] == 0 and 60 <= g.info["nplanes"] <= 68, g.info
+    rng = np.random.default_rng(5)
+    dirty = g.vis2dirty(c["vis"], c["wgt"])
+    ix = np.concatenate([rng.integers(0, nx, 13), [0, nx - 1, nx // 2]])
+    iy = np.concatenate([rng.integers(0, nx, 13), [0, nx - 1, nx // 2]])
+    ref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], c["mask"], nx, nx, c["cell"], c["cell"], 0.0, 0.0, False, True,
+                            False, True, False, pixels=(ix, iy))
+    assert rel(dirty[ix, iy], ref) < EPS
+    x = np.zeros((nx, nx))
+    px, py = rng.integers(0, nx, 200), rng.integers(0, nx, 200)
+    x[px, py] = rng.standard_normal(200)
+    x[0, 0], x[nx - 1, nx - 1] = 1.0, -1.0                         # the corners see the largest w-screen phase
+    vis = g.dirty2vis(x)
+    assert np.all(vis[c["mask"] == 0] == 0)
+    rows, chans = rng.integers(0, c["uvw"].shape[0], 3000), rng.integers(0, 8, 3000)
+    keep = c["mask"][rows, chans] != 0
+    rows, chans = rows[keep], chans[keep]
+    vref = dft.dft_dirty2vis(c["uvw"], c["freq"], x, c["cell"], c["cell"], 0.0, 0.0, False, True, False, True, False, rows=rows,
+                             chans=chans)
+    assert rel(vis[rows, chans], vref) < EPS
+    # adjointness <R x, y> == <x, R^H y> with y = the (masked) data
+    y = c["vis"] * c["mask"]
+    lhs, rhs = np.vdot(vis, y).real, np.vdot(x, g.vis2dirty(y))
+    assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs))
+    g.close()

@@ -93,3 +93,35 @@ def test_c2_adjointness_and_hessian_identities(c2):
     hb = g.hessian(x, beam=beam, eta=0.25, wsum=wsum)
     ref = beam * g.hessian(x * beam) / wsum + 0.25 * x
     assert np.linalg.norm(hb - ref) / np.linalg.norm(ref) < 1e-10
+
+
+def test_c3_device_cg_equals_host_loop_on_the_c2_operator(c2):
+    """BASELINE config C3, single-GPU leg: the per-band PCG solve on the C2 operator.  K iterations of the on-device CG
+    (pfbhip_gridder_cg: Hessian applies and CG vectors stay in HBM) give the iterate of the reference's loop
+    (opt/pcg.py:122-199: alpha / beta updates, stop on the relative change of the iterate) run on the host around
+    Gridder.hessian, and the loops stop at the same iteration for a loose tolerance."""
+    from pfb_imaging_amd import opt
+
+    c, g = c2
+    g.set_weights(c["wgt"])
+    wsum = float(c["wgt"][c["mask"] != 0].sum())
+    eta = 1e-3  # SURVEY 8(d): eta = 1e-3 of the wsum-normalised operator
+    rng = np.random.default_rng(3)
+    # a band-limited right-hand side: the Hessian of a sparse sky (what a residual looks like)
+    sky = np.zeros((c["nx"], c["ny"]))
+    sky[rng.integers(0, c["nx"], 200), rng.integers(0, c["ny"], 200)] = 1.0 + rng.random(200)
+    b = g.hessian(sky, eta=eta, wsum=wsum)
+    K = 4
+    dev = g.cg(b, eta=eta, wsum=wsum, tol=0.0, maxit=K, minit=K)
+    assert g.last_cg["iters"] == K
+    host = opt._cg_host(lambda v: g.hessian(v, eta=eta, wsum=wsum), b, np.zeros_like(b), None, 0.0, K, K, 0, 10, False, "host")
+    assert np.linalg.norm(dev - host) / np.linalg.norm(host) < 1e-9
+    # the iterate moves towards the sky and the residual norm drops monotonically in the energy norm
+    r0 = np.linalg.norm(b)
+    rK = np.linalg.norm(g.hessian(dev, eta=eta, wsum=wsum) - b)
+    assert rK < 0.5 * r0
+    # stopping rule: both loops stop at the same iteration for tol = 1e-2
+    g.cg(b, eta=eta, wsum=wsum, tol=1e-2, maxit=30, minit=1)
+    it_dev = g.last_cg["iters"]
+    opt._cg_host(lambda v: g.hessian(v, eta=eta, wsum=wsum), b, np.zeros_like(b), None, 1e-2, 30, 1, 0, 10, False, "host")
+    assert it_dev == opt._cg_host.last["iters"] and 1 <= it_dev < 30
