@@ -142,8 +142,10 @@ def test_c5_wide_field_64_planes_spot_checks():
     vref = dft.dft_dirty2vis(c["uvw"], c["freq"], x, c["cell"], c["cell"], 0.0, 0.0, False, True, False, True, False, rows=rows,
                              chans=chans)
     assert rel(vis[rows, chans], vref) < EPS
-    # adjointness <R x, y> == <x, R^H y> with y = the (masked) data
+    # adjointness <R x, y> == <x, R^H y> with y = the (masked) data.  Both sides are sums of 1e8 random-phase terms that
+    # cancel to ~1e-4 of their Cauchy-Schwarz bound ||R x|| ||y||, so rounding (1e-13 per element through 64 planes of
+    # 20480-point transforms and the kernel correction) is measured against that bound, not against the cancelled sum
     y = c["vis"] * c["mask"]
     lhs, rhs = np.vdot(vis, y).real, np.vdot(x, g.vis2dirty(y))
-    assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs))
+    assert abs(lhs - rhs) <= 1e-11 * np.linalg.norm(vis) * np.linalg.norm(y)
     g.close()
