@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
-"""Headline benchmark: exact Hessian apply (degrid + grid with w-stacking and 2-D FFTs) on
-BASELINE.json's configs[1]: 1 band, 1e7 synthetic visibilities, 8192^2 image, one band per GPU.
+"""Headline benchmark of the measurement-operator hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python bench.py --gpus N --steps K --warmup W [--config C2]           (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one Hessian apply  out = R^H W R x  on every rank's band (inputs resident in HBM:
-tile-sorted visibilities, weights, image): the operator inside the per-band CG, which needs no
-communication.  When N > 1 the timed region also contains the band sum of the result images -- the
-reference's one exchange per major cycle (core/deconv.py:320-321) -- as ONE RCCL sum-to-root per
---reduce-every applies (default: once per K-apply solve).  Rank 0 prints ONE JSON line.
+Workloads (BASELINE.json `configs`; `--config`):
+  C2 (default, the configuration the metric is quoted on)  exact Hessian apply  out = R^H W R x  (degrid + FFTs + grid
+      with w-stacking), 1 band of 1e7 visibilities per GPU, 8192^2 image.  A step = one apply on every rank's band (the
+      operator inside the per-band CG, which needs no communication); when N > 1 the timed region also holds the band sum
+      of the result image -- ONE RCCL sum-to-root per --reduce-every applies (default: once per timed region).
+  C1  the same apply at the reference's CPU-runnable size (1e5 visibilities, 1024^2).
+  C5  the same apply at 1e8 visibilities, 16384^2 image, 64 ES-kernel w-planes.
+  C3  per-band PCG solve on the C2 operator, one band per GPU: a step = one CG iteration (Hessian apply + the CG vector
+      kernels, all in HBM: pfbhip_gridder_cg_dev); the timed region is ONE K-iteration solve followed by the RCCL
+      sum-to-root of the solution-residual image (core/deconv.py:320-321).
+  C4  SARA backward step: 4 bands of 4096^2 over the N GPUs, PSF-approximate Hessian (8192^2) + Psi / Psi^H
+      (self, db1, db2, db3; 3 levels) + l21 dual update with its per-iteration band all-reduce; a step = one primal-dual
+      iteration (pfbhip_primal_dual); the clock is the iteration loop alone (cubes resident in HBM).
+Rank 0 prints ONE JSON line.
 
-value      = whole-job visibility throughput: N * 2 * nactive / t_step (a Hessian apply touches
-             every unmasked visibility twice: degrid + grid), in Mvis/s.
-roofline   = the dominant device stage of the apply, timed live with HIP events on the handle's
-             stream (pfbhip_gridder_profile): achieved = algorithmic bytes per launch / average
-             launch duration (SURVEY.md section 8(d) accounting, restated in DESIGN.md).
-cpu_baseline = the oracle's CPU restatement (kind "port"; ducc0 itself is not installable) timed
-             on this box's host cores on a bounded sample (a few w-planes of the same workload).
+value        whole-job throughput: visibilities gridded + degridded per second (a Hessian apply touches every unmasked
+             visibility twice), N * 2 * nactive / t_step, in Mvis/s; C4: PSF-Hessian applies per second.
+roofline     the dominant device stage of the apply, timed live with HIP events on the handle's stream
+             (pfbhip_gridder_profile): achieved = compulsory bytes of one launch / average launch duration.
+             `actual_bytes_per_apply` / `actual_frac` sum the compulsory bytes of the PRUNED pipeline that runs (plus the
+             plane clear) -- the honest HBM fraction; `apply_frac` keeps SURVEY section 8(d)'s unpruned accounting.
+host_path    what a caller of the numpy-in / numpy-out surface sees (N = 1): hessian_slice, vis2dirty, dirty2vis per call.
+cpu_baseline ducc0 when importable on this box (kind "ducc0"), else the oracle's CPU restatement (kind "port") of the
+             same apply on this box's host cores.
 """
 
 import argparse
@@ -33,58 +43,62 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-# stage timer -> the kernel it brackets (name as rocprofv3 lists it)
-KERNEL_OF = {"grid": "k_grid_mp", "degrid": "k_degrid_mp", "fft_rows": "k_rowfft_plain", "pad": "k_b2a", "crop": "k_a2b",
-             "fft_crop": "k_fused_fft_crop", "pad_fft": "k_fused_pad_fft"}
+# stage timer -> the kernel it brackets (name as rocprofv3 lists it); the record scatter / row-walk gather / transposing
+# first-axis FFT replace k_grid_blk / k_degrid_mp / k_rowfft_plain + k_a2b / k_b2a where the plan admits them
+KERNEL_OF = {"grid": "k_grid_rec", "degrid": "k_degrid_rw", "fft_rows": "k_rowfft_a2b / k_rowfft_b2a", "pad": "k_b2a",
+             "crop": "k_a2b", "fft_crop": "k_fused_fft_crop", "pad_fft": "k_fused_pad_fft"}
 
 
 def algorithmic_bytes(info, nx, ny, nrow, nactive):
-    """compulsory traffic of one Hessian apply and of one launch per stage."""
+    """Compulsory traffic: SURVEY.md section 8(d) (unpruned, per apply) and, per launch of every stage, of the PRUNED
+    pipeline that runs.  Returns (survey bytes per apply, {stage: bytes per launch},
+    {stage: launches per apply}, other bytes per apply)."""
     Sc, Sr = 16, 8
     G = info["nu"] * info["nv"] * Sc
     I = nx * ny * Sr
     P = info["nplanes"]
     b_vis = nactive * (2 * Sc + Sr + 2) + 2 * nrow * 24
     b_grid = P * (12 * G + 3 * I)
-    # Per-launch compulsory bytes of the PRUNED pipeline actually run (DESIGN.md section 5): only the
-    # occupied rows of the uv-plane A (nu,nv) are cleared / scattered / transformed, the second axis runs
-    # on the cropped, transposed plane B (ny,nu), of which only the occupied columns are read / written.
-    # A launch = what the stage timers count (include/pfbhip.h, PFBHIP_NSTAGES).
-    occ = info["occ_rows"] / info["nu"]
-    B = ny * info["nu"] * Sc
-    ngroups = -(-P // 4)          # scatter / gather / fused second-axis launches per direction (<= 4 planes each)
-    ppl = P / ngroups             # planes per such launch
+    occ = info["occ_rows"] / info["nu"]      # occupied fraction of the uv-plane rows (only those are cleared / transformed)
+    B = ny * info["nu"] * Sc                 # cropped, transposed plane of the second axis
+    ngroups = -(-P // 4)                     # scatter / gather / fused second-axis launches per direction (<= 4 planes each)
+    ppl = P / ngroups                        # planes per such launch
     fused = bool(info.get("fft_mode", 0) & 2)
+    tfft = bool(info.get("fft_mode", 0) & 8)
+    rec = info.get("scatter_mode", 0) == 2
+    nsl = max(int(info.get("scatter_launches", 1)), 1)
+    vis_rec = 32 + (16 * ppl if rec else 40)  # per visibility and pass: record + values (k_grid_rec) / coordinates + value
     per_launch = {
-        "grid": ppl * (occ * G + nactive * (Sc + 24)),    # per plane: occupied plane rows written once + records read
-        "degrid": ppl * (occ * G + nactive * (Sc + 24)),  # per plane: occupied plane rows read once + records read
+        # occupied plane rows written (read-add-written by tile) once + the visibility records; one launch per tile colour
+        "grid": (ppl * occ * G + nactive * vis_rec) / nsl,
+        # occupied plane rows read once + records (+ the plane-weighted values it writes inside a Hessian apply)
+        "degrid": ppl * occ * G + nactive * (32 + 8 * ppl + (16 * ppl if rec else 16)),
     }
+    launches = {"grid": ngroups * nsl, "degrid": ngroups}
     if fused:
         per_launch.update({
-            "fft_rows": 2 * occ * G,                                  # first axis, one plane: read + write of the occupied rows
-            "pad": occ * B + occ * G,                                 # B -> A transpose with zero padding, one plane
-            "crop": occ * (ny / info["nv"]) * G + occ * B,            # A -> B transpose with crop, one plane
-            # planes read once; image written (first group) or read+written; the last launch also reads the correction
-            # image (the finalize is folded into it)
+            # planes read once; image written (first group) or read + written; the last launch also reads the correction
             "fft_crop": ppl * occ * B + I * (2 - 1 / ngroups) + I / ngroups,
-            # image and correction image read once per launch (x * corr is formed in the load); occupied columns written per plane
+            # image and correction read once per launch (x * corr is formed in the load); occupied columns written per plane
             "pad_fft": 2 * I + ppl * occ * B,
         })
+        launches.update({"fft_crop": ngroups, "pad_fft": ngroups})
+        if tfft:  # first axis with the crop / pad + transpose folded in: occupied rows of A on one side, occupied columns of B on the other
+            per_launch["fft_rows"] = occ * G + occ * B
+            launches["fft_rows"] = 2 * P
+        else:
+            per_launch.update({"fft_rows": 2 * occ * G, "pad": occ * B + occ * G, "crop": occ * (ny / info["nv"]) * G + occ * B})
+            launches.update({"fft_rows": 2 * P * 2, "pad": P, "crop": P})  # (two row spans per plane and direction)
+            per_launch["fft_rows"] /= 2
     else:
-        per_launch.update({
-            "fft_rows": occ * G + B,                                  # one row-FFT pass: 1 read + 1 write (average of the A and B passes)
-            "pad": (I + B + occ * B + occ * G) / 2,                   # pad+screen (image -> B) and transpose+pad (B -> occupied A)
-            "crop": (occ * (ny / info["nv"]) * G + B + (nx / info["nu"]) * B + 2 * I) / 2,  # A -> B, B -> image RMW
-        })
-    return b_vis + b_grid, per_launch
+        per_launch.update({"fft_rows": occ * G + B, "pad": (I + B + occ * B + occ * G) / 2,
+                           "crop": (occ * (ny / info["nv"]) * G + B + (nx / info["nu"]) * B + 2 * I) / 2})
+        launches.update({"fft_rows": 4 * P, "pad": 2 * P, "crop": 2 * P})
+    other = P * occ * G  # clearing the occupied rows of the scatter's planes (memset; on a side stream in single-pass plans)
+    return b_vis + b_grid, per_launch, launches, other
 
 
-def cpu_baseline(case, ginfo, oracle_params, nplanes_sample=2):
-    """Oracle (CPU port) timing of `nplanes_sample` w-planes of the same Hessian apply."""
-    from oracle import _lib as olib
-    from oracle import wgridder as owg
-
-    # threads = this process's CPU share (cgroup quota / affinity), not the host's core count
+def host_threads():
     nthr = len(os.sched_getaffinity(0))
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -92,36 +106,127 @@ def cpu_baseline(case, ginfo, oracle_params, nplanes_sample=2):
             nthr = min(nthr, max(1, int(int(quota) / int(period))))
     except Exception:
         pass
-    nthr = int(os.environ.get("PFB_CPU_THREADS", min(nthr, 16)))
+    return int(os.environ.get("PFB_CPU_THREADS", min(nthr, 16)))
+
+
+def cpu_baseline(case, oracle_params, budget_s=60.0):
+    """ducc0 on this box's host cores when it can be imported, else the oracle's CPU
+    restatement of the same Hessian apply -- the whole apply when it fits the budget, else a bounded sample of planes."""
+    c = case
+    nthr = host_threads()
+    wgt = np.ascontiguousarray(c["wgt"], dtype=np.float64)
+    try:
+        import ducc0  # noqa: F401
+        from ducc0.wgridder.experimental import dirty2vis, vis2dirty
+
+        kw = dict(uvw=c["uvw"], freq=c["freq"], pixsize_x=c["cell"], pixsize_y=c["cell"], center_x=0.0, center_y=0.0, epsilon=1e-7,
+                  flip_u=False, flip_v=True, flip_w=False, do_wgridding=True, divide_by_n=False, nthreads=nthr, sigma_min=1.1,
+                  sigma_max=3.0)
+        ts = []
+        for i in range(3):
+            t0 = time.time()
+            mv = dirty2vis(dirty=c["x"], mask=c["mask"], **kw)
+            vis2dirty(vis=mv, wgt=wgt, mask=c["mask"], npix_x=c["nx"], npix_y=c["ny"], double_precision_accumulation=True, **kw)
+            ts.append(time.time() - t0)
+        t_apply = float(np.median(ts[1:]))
+        nactive = int((c["mask"] != 0).sum())
+        return {"value": 2 * nactive / t_apply / 1e6, "unit": "Mvis/s", "cores": nthr, "kind": "ducc0",
+                "version": getattr(ducc0, "__version__", "?"), "sample": f"median of 2 whole applies after 1 warm-up, {nthr} threads",
+                "sec_per_apply": t_apply}
+    except ImportError:
+        pass
+    from oracle import _lib as olib
+    from oracle import wgridder as owg
+
     olib.lib().pfbo_set_num_threads(nthr)
     owg.FFT_WORKERS = nthr
-    c = case
     t0 = time.time()
-    plan = owg.Plan(c["uvw"], c["freq"], c["mask"], c["nx"], c["ny"], c["cell"], c["cell"], 0.0, 0.0, 1e-7, False,
-                    True, False, True, False, params=oracle_params)
+    plan = owg.Plan(c["uvw"], c["freq"], c["mask"], c["nx"], c["ny"], c["cell"], c["cell"], 0.0, 0.0, 1e-7, False, True, False, True,
+                    False, params=oracle_params)
     t_plan = time.time() - t0
     P = plan.p.nplanes
-    planes = sorted(set(np.linspace(0, P - 1, nplanes_sample).round().astype(int).tolist()))
-    swgt = np.ascontiguousarray(c["wgt"], dtype=np.float64).reshape(-1)
+    swgt = wgt.reshape(-1)
     acc_img = np.zeros((c["nx"], c["ny"]))
     sacc = np.zeros(plan.nrow * plan.nchan, dtype=np.complex128)
     dc = np.ascontiguousarray(c["x"])
-    t0 = time.time()
-    for p in planes:
+    done, t = 0, 0.0
+    for p in range(P):  # plane by plane until the whole apply or the budget is done
+        t0 = time.time()
         plan.plane_round_trip(dc, swgt, p, acc_img, sacc)
-    t = time.time() - t0
-    t_apply = t / len(planes) * P
+        t += time.time() - t0
+        done += 1
+        if t > budget_s and done < P:
+            break
+    t_apply = t / done * P
     nactive = int(plan.active.sum())
-    return {
-        "value": 2 * nactive / t_apply / 1e6,
-        "unit": "Mvis/s",
-        "cores": int(olib.lib().pfbo_num_threads()),
-        "kind": "port",
-        "sample": f"{len(planes)} of {P} w-planes of the same apply (all {nactive} vis, {c['nx']}^2 image, "
-                  f"grid {plan.p.nu}x{plan.p.nv}); {t:.1f} s measured, scaled by {P}/{len(planes)}",
-        "sec_per_apply_est": t_apply,
-        "plan_sec": t_plan,
-    }
+    whole = done == P
+    return {"value": 2 * nactive / t_apply / 1e6, "unit": "Mvis/s", "cores": int(olib.lib().pfbo_num_threads()), "kind": "port",
+            "sample": (f"the whole apply ({P} w-planes" if whole else f"{done} of {P} w-planes of the same apply (scaled by {P}/{done}") +
+                      f", all {nactive} vis, {c['nx']}^2 image, grid {plan.p.nu}x{plan.p.nv}); {t:.1f} s measured; ducc0 is not "
+                      "importable on this box -- this is the repository's restatement, not the reference's speed",
+            "sec_per_apply": t_apply, "plan_sec": t_plan}
+
+
+def host_path(case, g, wsum, reps=3):
+    """The callable surface as `pfb kclean / sara / fluxtractor` see it: numpy in, numpy out, plan cache keyed on content."""
+    from pfb_imaging_amd import wgridder as wg
+    from pfb_imaging_amd.operators.hessian import hessian_slice
+
+    c = case
+    out = {}
+    hkw = dict(uvw=c["uvw"], weight=c["wgt"], vis_mask=c["mask"], freq=c["freq"], beam=None, cell=c["cell"], x0=0.0, y0=0.0,
+               do_wgridding=True, epsilon=1e-7, eta=1e-3, wsum=wsum)
+    xout = np.empty_like(c["x"])
+
+    def timed(fn):
+        fn()  # first call builds / binds (plan, weights): not timed
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3
+
+    out["hessian_slice_ms"] = timed(lambda: hessian_slice(c["x"], **hkw))   # returns a new array (page-locked: D2H at the PCIe rate)
+    # caller-owned pageable xout: the runtime stages the device-to-host copy (~12 GB/s on this host)
+    out["hessian_slice_pageable_xout_ms"] = timed(lambda: hessian_slice(c["x"], xout=xout, **hkw))
+    # the same arrays handed out read-only (the form Ray gives the band workers): hashed once, then recognised by address
+    ro = {k: c[k].view() for k in ("uvw", "wgt", "mask", "freq")}
+    for v in ro.values():
+        v.flags.writeable = False
+    frozen = dict(hkw, uvw=ro["uvw"], weight=ro["wgt"], vis_mask=ro["mask"], freq=ro["freq"])
+    frozen_ok = all(not v.flags.writeable and v.base is not None and not v.base.flags.writeable for v in ro.values())
+    if not frozen_ok:  # views of writeable arrays stay writeable through their base: freeze copies instead
+        for k in ro:
+            ro[k] = c[k].copy()
+            ro[k].flags.writeable = False
+        frozen = dict(hkw, uvw=ro["uvw"], weight=ro["wgt"], vis_mask=ro["mask"], freq=ro["freq"])
+    out["hessian_slice_readonly_inputs_ms"] = timed(lambda: hessian_slice(c["x"], **frozen))
+    x_host = c["x"]
+    out["handle_hessian_ms"] = timed(lambda: g.hessian(x_host, eta=1e-3, wsum=wsum))
+    skw = dict(uvw=c["uvw"], freq=c["freq"], mask=c["mask"], pixsize_x=c["cell"], pixsize_y=c["cell"], center_x=0.0, center_y=0.0,
+               epsilon=1e-7, flip_u=False, flip_v=True, flip_w=False, do_wgridding=True, divide_by_n=False, sigma_min=1.1,
+               sigma_max=2.6)
+    vis = c.get("vis")
+    if vis is None:
+        rng = np.random.default_rng(0)
+        vis = rng.standard_normal(c["mask"].shape) + 1j * rng.standard_normal(c["mask"].shape)
+    out["vis2dirty_ms"] = timed(lambda: wg.vis2dirty(vis=vis, wgt=c["wgt"], npix_x=c["nx"], npix_y=c["ny"], **skw))
+    out["dirty2vis_ms"] = timed(lambda: wg.dirty2vis(dirty=c["x"], **skw))
+    from pfb_imaging_amd._lib import DeviceArray
+
+    t0 = time.perf_counter()
+    d = DeviceArray.from_host(c["x"])
+    t1 = time.perf_counter()
+    d.download()
+    t2 = time.perf_counter()
+    d.free()
+    nb = c["x"].nbytes
+    out["h2d_gbs"], out["d2h_gbs"] = nb / (t1 - t0) / 1e9, nb / (t2 - t1) / 1e9
+    out["note"] = ("ms per call, numpy in / numpy out, median of %d after one untimed call; the image crosses PCIe once each way per "
+                   "Hessian (%.0f MB), the stateless calls also hash their inputs (plan-cache key)" % (reps, nb / 1e6))
+    wg.clear_cache()
+    return out
 
 
 def main():
@@ -129,14 +234,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C2", help="C2 (headline), C1, C4 or 'nrow,nchan,npix'")
+    ap.add_argument("--config", default="C2", help="C2 (headline), C1, C3, C4, C5 or 'nrow,nchan,npix[,zscale]'")
     ap.add_argument("--epsilon", type=float, default=1e-7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-planes", type=int, default=2)
+    ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU work for the baseline sample")
     ap.add_argument("--force", default=None, help="developer knob: 'sigma,W' pins the kernel row")
     ap.add_argument("--verbosity", type=int, default=0)
     ap.add_argument("--reduce-every", type=int, default=0,
-                    help="band reduce (RCCL sum-to-root) every this many applies; 0 = once per timed region")
+                    help="C2: band reduce (RCCL sum-to-root) every this many applies; 0 = once per timed region")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON of rank 0: native libraries (RCCL prints a version banner on fd 1 when
@@ -152,9 +258,8 @@ def main():
     from pfb_imaging_amd.wgridder import Gridder
 
     _lib.require_gpu()  # fail loudly: no CPU path
-    # RCCL carries the band reduce.  The timed Hessian applies need no communication, so a communicator that fails to
-    # come up (all ranks agree on that over the gloo rendezvous) costs the reduce, not the measurement: it is then
-    # reported as skipped in config.parallelism.
+    # RCCL carries the band exchanges.  A communicator that fails to come up (all ranks agree on that over the gloo
+    # rendezvous) costs the exchange, not the per-band measurement: it is then reported as skipped in config.parallelism.
     rccl_error = None
     try:
         comm = BandComm.from_env()
@@ -166,26 +271,45 @@ def main():
         _lib.check(_lib.lib().pfbhip_set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(_lib.device_count(), 1)))
     if comm.world_size > 1 and comm.min_over_ranks(0.0 if rccl_error else 1.0) == 0.0 and rccl_error is None:
         rccl_error = "RCCL communicator failed on another rank"
-    use_reduce = comm.world_size > 1 and rccl_error is None
+    use_rccl = comm.world_size > 1 and rccl_error is None
     if rccl_error is not None:
-        print(f"[bench rank {comm.rank}] RCCL unavailable, band reduce skipped: {rccl_error}", file=sys.stderr, flush=True)
+        print(f"[bench rank {comm.rank}] RCCL unavailable, band exchange skipped: {rccl_error}", file=sys.stderr, flush=True)
         if comm.transport == "rccl":  # ours came up but a peer's did not: stay off it
             comm.transport = "gloo"
     rank, world = comm.rank, comm.world_size
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
+    if args.config == "C4":
+        out = bench_c4(args, comm, use_rccl, rccl_error)
+    else:
+        out = bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray, _lib)
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    comm.barrier()
+    comm.close()
+
+
+def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray, _lib):
+    rank, world = comm.rank, comm.world_size
+    solve = args.config == "C3"
+    cfg = "C2" if solve else args.config
     # ---- this rank's band -------------------------------------------------
-    if args.config in synth.CONFIGS:
-        case = synth.make_config(args.config, band=rank)
-        wl = f"{args.config}: 1 band/GPU, {synth.CONFIGS[args.config][0]}x{synth.CONFIGS[args.config][1]} vis, " \
-             f"{synth.CONFIGS[args.config][2]}^2 image, exact Hessian apply (degrid+FFT+grid), double precision"
+    if cfg in synth.CONFIGS:
+        case = synth.make_config(cfg, band=rank, with_vis=(world == 1 and cfg in ("C1", "C2")))
+        nrow_c, nchan_c, npix_c, _ = synth.CONFIGS[cfg]
+        what = "per-band PCG solve (on-device CG around the exact Hessian) + RCCL reduce of the image" if solve else \
+            "exact Hessian apply (degrid+FFT+grid)"
+        wl = f"{args.config}: 1 band/GPU, {nrow_c}x{nchan_c} vis, {npix_c}^2 image, {what}, double precision"
+        size_txt = f"{npix_c}^2 grid, {nrow_c * nchan_c:.0e} vis/band".replace("e+0", "e")
     else:
         parts = args.config.split(",")
         nrow, nchan, npix = (int(v) for v in parts[:3])
         zscale = float(parts[3]) if len(parts) > 3 else 1e-3
-        case = synth.make_case(nrow, nchan, npix, zscale=zscale, seed=rank)
+        case = synth.make_case(nrow, nchan, npix, zscale=zscale, seed=rank, with_vis=False)
         wl = f"custom {nrow}x{nchan} vis, {npix}^2 image, antenna z-scale {zscale}"
+        size_txt = f"{npix}^2 grid, {nrow * nchan:.0e} vis/band".replace("e+0", "e")
     nx, ny = case["nx"], case["ny"]
     t0 = time.time()
     g = Gridder(case["uvw"], case["freq"], case["mask"], npix_x=nx, npix_y=ny, pixsize_x=case["cell"],
@@ -199,32 +323,44 @@ def main():
     x_dev = DeviceArray.from_host(case["x"])
     out_dev = DeviceArray((nx, ny), np.float64)
     red_dev = DeviceArray((nx, ny), np.float64) if (world > 1 and rank == 0) else None
+    eta = 1e-3  # Tikhonov term of the wsum-normalised operator (C3); the plain apply uses 0
 
-    # A step = one exact Hessian apply of this rank's band: the inner operator of the per-band CG, which needs no
-    # communication ("CG itself needs no communication").  The band sum of the result image -- the one
-    # exchange of the reference's major cycle (core/deconv.py:320-321) -- is ONE RCCL sum-to-root every
-    # --reduce-every applies (default: once per timed region, i.e. once per K-apply solve), inside the timed region.
-    reduce_every = args.reduce_every if args.reduce_every > 0 else max(args.steps, 1)
-    nstep = [0]
+    if solve:
+        # One timed region = ONE solve of exactly K CG iterations per band (tol = 0, minit = maxit = K; everything in HBM)
+        # + the band reduce of the result.  Warm-up: W-iteration solves.
+        def run(k):
+            g.cg_dev(x_dev, out_dev, eta=eta, wsum=wsum, tol=0.0, maxit=k, minit=k)
+            if use_rccl:
+                comm.reduce_sum_dev(out_dev, red_dev, root=0)
 
-    def step():
-        g.hessian_dev(x_dev, out_dev, eta=0.0, wsum=wsum)
-        nstep[0] += 1
-        if use_reduce and nstep[0] % reduce_every == 0:
+        if args.warmup > 0:
+            run(args.warmup)
+        reduce_every = args.steps
+    else:
+        reduce_every = args.reduce_every if args.reduce_every > 0 else max(args.steps, 1)
+        nstep = [0]
+
+        def step():
+            g.hessian_dev(x_dev, out_dev, eta=0.0, wsum=wsum)
+            nstep[0] += 1
+            if use_rccl and nstep[0] % reduce_every == 0:
+                comm.reduce_sum_dev(out_dev, red_dev, root=0)
+
+        for _ in range(args.warmup):
+            step()
+        if use_rccl:  # warm the communicator (first-call setup is not part of a step)
             comm.reduce_sum_dev(out_dev, red_dev, root=0)
-
-    for _ in range(args.warmup):
-        step()
-    if use_reduce:  # warm the communicator (first-call setup is not part of a step)
-        comm.reduce_sum_dev(out_dev, red_dev, root=0)
-    nstep[0] = 0
+        nstep[0] = 0
     comm.barrier()
     _lib.check(_lib.lib().pfbhip_synchronize())
     g.profile(True)
     g.profile_get(reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if solve:
+        run(args.steps)
+    else:
+        for _ in range(args.steps):
+            step()
     _lib.check(_lib.lib().pfbhip_synchronize())
     comm.barrier()
     elapsed = time.perf_counter() - t0
@@ -233,29 +369,30 @@ def main():
     elapsed = comm.max_over_ranks(elapsed)
     total_active = comm.sum_over_ranks(g.nactive)
     ms_per_step = elapsed / args.steps * 1e3
-
+    out = None
     if rank == 0:
-        b_apply, per_launch = algorithmic_bytes(info, nx, ny, case["uvw"].shape[0], g.nactive)
-        # the register-footprint scatter runs one launch per tile colour: each moves a quarter of the pass's bytes
-        nsl = max(int(info["scatter_launches"]), 1)
-        per_launch["grid"] /= nsl
+        b_apply, per_launch, launches, other_bytes = algorithmic_bytes(info, nx, ny, case["uvw"].shape[0], g.nactive)
         dom = max((s for s in stages if s in per_launch and stages[s][1]), key=lambda s: stages[s][0])
         dom_ms, dom_calls = stages[dom]
         avg_ms = dom_ms / max(dom_calls, 1)
         achieved = per_launch[dom] / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        # the PMC passes were collected on the headline configuration only
-        if os.path.exists(tfile) and args.config == "C2" and args.epsilon == 1e-7 and args.force is None:
-            try:
-                traffic = json.load(open(tfile)).get(dom)
-            except Exception:
-                traffic = None
         stage_ms = {s: round(v[0] / args.steps, 3) for s, v in stages.items()}
         stage_launches = {s: v[1] / args.steps for s, v in stages.items()}
+        actual = sum(per_launch[s] * stages[s][1] / args.steps for s in per_launch if stages[s][1]) + other_bytes
+        apply_s = elapsed / args.steps
+        names = dict(KERNEL_OF)
+        if info["scatter_mode"] != 2:
+            names["grid"] = "k_grid_blk" if info["scatter_mode"] == 1 else "k_grid_mp"
+        if not info["fft_mode"] & 8:
+            names["fft_rows"] = "k_rowfft_plain"
+        scatter_txt = {2: f"record-driven register footprint (k_grid_rec), {info['scatter_launches']} launch(es) per pass",
+                       1: f"register footprint (k_grid_blk), {info['scatter_launches']} launch(es) per pass",
+                       0: "diagonal walk (k_grid_mp)"}[info["scatter_mode"]]
+        metric = f"Mvis/s gridded+degridded in exact Hessian applies ({size_txt})" if not solve else \
+            f"Mvis/s gridded+degridded inside per-band PCG solves ({size_txt}, one band per GPU, RCCL reduce of the image)"
         out = {
-            "metric": "Mvis/s gridded+degridded in exact Hessian applies (8192^2 grid, 1e7 vis/band)",
-            "value": total_active * 2 / (elapsed / args.steps) / 1e6,
+            "metric": metric,
+            "value": total_active * 2 / apply_s / 1e6,
             "unit": "Mvis/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -266,67 +403,138 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "hessian_applies_per_s": world / (elapsed / args.steps),
+            "hessian_applies_per_s": world / apply_s,
             "config": {
-                "workload": wl, "bands": world, "w_scheme": "polynomial planes" if info["wmode"] == 1 else "ES-kernel planes", "vis_per_band": int(case["uvw"].shape[0] * case["freq"].size),
-                "active_vis_per_band": int(g.nactive), "image": [nx, ny], "epsilon": args.epsilon,
-                "grid": [info["nu"], info["nv"]], "occupied_rows": info["occ_rows"], "w_planes": info["nplanes"],
-                "kernel_support": info["W"], "scatter": (f"register footprint (k_grid_blk), {info['scatter_launches']} launch(es) per pass" if info["scatter_mode"] == 1 else "diagonal walk (k_grid_mp)"), "plane_transform": ("own row FFT" if info["fft_mode"] & 1 else "rocFFT rows") +
+                "workload": wl, "bands": world,
+                "w_scheme": "polynomial planes" if info["wmode"] == 1 else "ES-kernel planes",
+                "vis_per_band": int(case["uvw"].shape[0] * case["freq"].size), "active_vis_per_band": int(g.nactive),
+                "image": [nx, ny], "epsilon": args.epsilon, "grid": [info["nu"], info["nv"]], "occupied_rows": info["occ_rows"],
+                "w_planes": info["nplanes"], "kernel_support": info["W"], "scatter": scatter_txt,
+                "gather": "row walk, DPP-broadcast FMAs (k_degrid_rw)" if (info["scatter_mode"] == 2 or info["nplanes"] <= 4 and info["wmode"] == 1) else "diagonal walk (k_degrid_mp)",
+                "plane_transform": ("own row FFT" if info["fft_mode"] & 1 else "rocFFT rows") +
+                (" with the transposes folded in" if info["fft_mode"] & 8 else "") +
                 (" + fused second axis" if info["fft_mode"] & 2 else
                  (" + own second axis (unfused)" if info["fft_mode"] & 4 else " + rocFFT second axis")),
-                "sigma": info["sigma"], "parallelism": f"band-per-gpu x{world}" + (f" + 1 RCCL sum-to-root of the image per {reduce_every} applies" if use_reduce else
-                                                                   (f" (band reduce skipped: {rccl_error})" if rccl_error else "")),
+                "sigma": info["sigma"],
+                "parallelism": f"band-per-gpu x{world}" + (
+                    (f" + 1 RCCL sum-to-root of the image per {'solve' if solve else str(reduce_every) + ' applies'}") if use_rccl else
+                    (f" (band reduce skipped: {rccl_error})" if rccl_error else "")),
                 "plan_seconds": round(t_plan, 2),
             },
             "roofline": {
-                "bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "bound": "hbm", "kernel": names.get(dom, dom), "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                # not measured in this run: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) are separate runs, see profiles/
+                "traffic": None, "traffic_profile": "profiles/r02_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
                 "alg_bytes_per_launch": per_launch[dom], "avg_launch_ms": avg_ms, "launches": dom_calls,
+                "actual_bytes_per_apply": actual,
+                "actual_frac": actual / apply_s / 1e9 / HBM_PEAK_GBS,
+                "actual_note": "sum over stages of (compulsory bytes per launch of the pruned pipeline x launches) + the plane clear; "
+                               + ("per CG iteration, the CG vector kernels (~10 image passes) not counted" if solve else "per apply"),
                 "apply_alg_bytes": b_apply,
-                "apply_frac": b_apply / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                "apply_frac": b_apply / apply_s / 1e9 / HBM_PEAK_GBS,
+                "apply_frac_note": "SURVEY.md section 8(d) UNPRUNED accounting (every plane row and the full second axis); the "
+                                   "pipeline that runs moves actual_bytes_per_apply",
                 "stage_ms_per_step": stage_ms,
                 "stage_launches_per_step": stage_launches,
                 "stage_achieved_gbs": {s: round(per_launch[s] / (stages[s][0] / max(stages[s][1], 1) * 1e-3) / 1e9, 1)
                                        for s in per_launch if stages[s][1]},
             },
         }
-        if dom == "grid" and info["scatter_mode"] == 1:
-            # Register-footprint scatter: no LDS atomic per tap; what a visibility costs is f64
-            # VALU work -- per held cell one product and 2 FMAs per plane, NR cells per lane, plus the 13-step Horner
-            # chain of the kernel values -- at 4 cycles per wave64 f64 instruction on each of the 1024 SIMDs.
-            out["roofline"]["kernel"] = "k_grid_blk"
+        if dom == "grid" and info["scatter_mode"] in (1, 2):
+            # Register-footprint scatters: no LDS atomic per tap; what a visibility costs is VALU
+            # issue -- per held cell one product and 2 FMAs per plane, NR (- 1 for the record kernel at W = 16) cells per
+            # lane, plus the kernel evaluation -- at 4 cycles per wave64 f64 instruction on each of the 1024 SIMDs.
             ngroups = -(-info["nplanes"] // 4)
             kp = info["nplanes"] / ngroups
             nr = -(-(info["W"] + 3) // 3)
-            f64_ops = nr * (1 + 2 * kp) + 13
+            if info["scatter_mode"] == 2 and (info["W"] + 3) % 3 == 1:
+                nr -= 1
+            f64_ops = nr * (1 + 2 * kp) + 14
+            nsl = max(int(info["scatter_launches"]), 1)
             floor_ms = g.nactive * f64_ops * 4 / (256 * 4) / 2.4e9 * 1e3 / nsl   # per launch
             out["roofline"]["limiter"] = {
                 "bound": "valu_f64", "f64_wave_instr_per_vis": f64_ops, "cycles_per_instr": 4, "simds": 1024,
                 "clock_ghz": 2.4, "launches_per_pass": nsl, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
-                "note": "counted f64 FMA/MUL only; rocprofv3 SQ counters (profiles/) give 107 VALU instructions per "
-                        "visibility and ~50 % VALU-busy, the rest is LDS flush + tile load/store phases",
+                "note": "counted f64 FMA/MUL only; a wave issues one instruction of any kind per 4 cycles, so scalar / LDS / "
+                        "wait instructions cost issue slots too (tools/stamp_scatter.py: in-kernel phase stamps)",
             }
-        elif dom == "grid":
-            # The diagonal-walk scatter is bound by the LDS f64-atomic pipe, not by HBM:
-            # 2*16*16 ds_add_f64 lane-operations per visibility and plane, ~12 cycles per wave-instruction.
-            ngroups = -(-info["nplanes"] // 4)
-            winstr = g.nactive * (info["nplanes"] / ngroups) * 512 / 64          # wave-instructions per launch
-            floor_ms = winstr / 256 * 12 / 2.4e9 * 1e3                           # 256 CUs, 2.4 GHz
-            out["roofline"]["limiter"] = {
-                "bound": "lds_atomic", "wave_instr_per_launch": winstr, "cycles_per_instr": 12, "cus": 256,
-                "clock_ghz": 2.4, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
-            }
+        if world == 1 and not args.no_host_path and cfg in ("C1", "C2") and not solve:
+            try:
+                out["host_path"] = host_path(case, g, wsum)
+            except Exception as e:
+                out["host_path"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(case, info, g.oracle_params(), args.cpu_planes)
+                out["cpu_baseline"] = cpu_baseline(case, g.oracle_params(), args.cpu_budget)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mvis/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    comm.barrier()
     g.close()
-    comm.close()
+    return out
+
+
+def bench_c4(args, comm, use_rccl, rccl_error):
+    """BASELINE config C4: the SARA backward step on 4 bands of 4096^2 (PSF 8192^2), bands sharded b % N."""
+    from pfb_imaging_amd import prox
+    from pfb_imaging_amd.operators.band_worker import BandWorkerPool
+    from pfb_imaging_amd.operators.hessian import HessPSF, HessTreeRay
+    from pfb_imaging_amd.operators.psi import PsiNocopyt
+    from pfb_imaging_amd.opt import L21, PrimalDual, PsfGrad
+
+    rank, world = comm.rank, comm.world_size
+    nband, n, npsf = 4, 4096, 8192
+    bases, nlevel = ("self", "db1", "db2", "db3"), 3
+    rng = np.random.default_rng(4)  # same data on every rank
+    ky = np.fft.fftfreq(npsf)[:, None] ** 2
+    kx = np.fft.rfftfreq(npsf)[None, :] ** 2
+    psfhat = np.stack([np.exp(-(ky + kx) * (3.0e4 + 1.0e4 * b)) for b in range(nband)])
+    eta = np.full(nband, 0.05)
+    model = np.abs(rng.standard_normal((nband, n, n))) * (rng.random((nband, n, n)) > 0.99)
+    xtilde = model + 0.1 * rng.standard_normal(model.shape)
+    psi = PsiNocopyt(nband, n, n, bases, nlevel, 1)
+    reg = L21(psi, bases, nu=np.sqrt(len(bases)))
+    if world == 1:
+        hess = HessPSF(n, n, psfhat, beam=None, eta=eta)
+    else:
+        pool = BandWorkerPool(nband, comm=comm if use_rccl else None)
+        parts = [[dict(psfhat=psfhat[b][None], beam=np.ones((1, n, n)), wsum=np.ones(1))] for b in range(nband)]
+        hess = HessTreeRay(parts, n, n, npsf, npsf, etas=eta, wsums=np.ones(nband), workers=pool)
+
+    def run(k):
+        pd = PrimalDual(tol=0.0, maxit=k, verbosity=0, gamma=1.0, primal_prox=prox.positivity_prox(1))
+        pd.setup(reg, 1.0 + eta.max())
+        pd.set_grad(PsfGrad(hess, xtilde, 1.0))
+        if pd._device_path() is None:
+            raise SystemExit("C4: the device-resident primal-dual loop is not available for this layout")
+        pd.solve(model.copy(), 0.01)
+        return pd.last
+
+    if args.warmup > 0:
+        run(args.warmup)
+    comm.barrier()
+    t0 = time.perf_counter()
+    last = run(args.steps)
+    comm.barrier()
+    wall = comm.max_over_ranks(time.perf_counter() - t0)
+    loop_s = comm.max_over_ranks(float(last.get("loop_ms", 0.0)) * 1e-3) or wall
+    out = None
+    if rank == 0:
+        per = loop_s / args.steps
+        out = {
+            "metric": "PSF-approximate Hessian applies/s inside the SARA primal-dual step (4 bands, 4096^2, Psi: self+db1+db2+db3, 3 levels)",
+            "value": nband / per, "unit": "Hessian-applies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": per * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C4: SARA backward step, 4 bands x 4096^2, PSF 8192^2, a step = one primal-dual iteration "
+                                   "(Psi^H, l21 dual update, Psi, PSF Hessian, primal step, positivity)",
+                       "bands": nband, "image": [n, n], "psf": [npsf, npsf], "bases": list(bases), "nlevels": nlevel,
+                       "clock": "iteration loop of pfbhip_primal_dual (cubes resident in HBM); wall time of the call incl. "
+                                f"uploads / downloads: {wall / args.steps * 1e3:.2f} ms per iteration",
+                       "parallelism": f"bands b % {world}" + (" + 1 RCCL all-reduce of the band sum and 1 of the norms per iteration"
+                                                              if use_rccl else (f" (RCCL skipped: {rccl_error})" if rccl_error else ""))},
+        }
+    return out
 
 
 if __name__ == "__main__":

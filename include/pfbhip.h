@@ -51,6 +51,10 @@ int64_t pfbhip_good_size(int64_t n, int real);
  * plan caches on it: the reference's ducc0 calls are stateless (operators/gridder.py:590-613), so a cached plan is
  * reused only for byte-identical uvw / freq / mask / weights / psfhat. */
 uint64_t pfbhip_hash64(const void *data_host, size_t nbytes);
+/* Page-locked host buffers for result arrays (device-to-host copies into pinned memory run at the PCIe rate; into
+ * pageable memory the runtime stages them at a fraction of it). */
+int pfbhip_host_alloc(void **ptr_host, size_t bytes);
+int pfbhip_host_free(void *ptr_host);
 int pfbhip_malloc(void **ptr_dev, size_t bytes);
 int pfbhip_free(void *ptr_dev);
 int pfbhip_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
@@ -238,6 +242,9 @@ int pfbhip_psfconv_cg(pfbhip_psfconv *p, int64_t nparts, const int64_t *psf_slot
 /* A = beam * R^H W R (beam * .) / wsum + eta * I   (exact Hessian, weights bound by set_weights) */
 int pfbhip_gridder_cg(pfbhip_gridder *g, const double *beam_host, double eta, double wsum, const double *rhs_host,
                       double *x_host, int has_x0, double tol, int maxit, int minit, pfbhip_cg_info *info);
+/* The same solve with rhs / x / beam resident in HBM (bench, band workers that keep their images on the device). */
+int pfbhip_gridder_cg_dev(pfbhip_gridder *g, const double *beam_dev, double eta, double wsum, const double *rhs_dev,
+                          double *x_dev, int has_x0, double tol, int maxit, int minit, pfbhip_cg_info *info);
 
 /* ---- power method on the device (spectral norm of a Hessian) ------------
  * Replaces power_method / power_method_numba (src/pfb_imaging/opt/power_method.py:40-148) as called on
@@ -340,6 +347,7 @@ typedef struct pfbhip_pd_info {
     int32_t iters;
     int32_t status; /* 0 converged, 1 maxit reached */
     double eps;
+    double loop_ms; /* wall time of the iteration loop alone (cubes resident in HBM: uploads / downloads excluded) */
 } pfbhip_pd_info;
 int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs /* [nband] */, int64_t nband, const int64_t *nparts, const int64_t *psf_slots,
                        const int64_t *beam_slots, const double *scale, const double *eta, const double *xtilde_host, double gamma,

@@ -46,7 +46,7 @@ class GridderInfo(ct.Structure):
 
 
 class PDInfo(ct.Structure):
-    _fields_ = [("iters", i32), ("status", i32), ("eps", f64)]
+    _fields_ = [("iters", i32), ("status", i32), ("eps", f64), ("loop_ms", f64)]
 
 
 class PMInfo(ct.Structure):
@@ -61,7 +61,7 @@ class CGInfo(ct.Structure):
 SYMBOLS = (
     "pfbhip_last_error", "pfbhip_device_count", "pfbhip_set_device", "pfbhip_get_device", "pfbhip_device_name",
     "pfbhip_mem_info", "pfbhip_resize_thread_pool", "pfbhip_thread_pool_size", "pfbhip_good_size",
-    "pfbhip_hash64", "pfbhip_malloc", "pfbhip_free", "pfbhip_memcpy_h2d", "pfbhip_memcpy_d2h", "pfbhip_memcpy_d2d", "pfbhip_memset",
+    "pfbhip_hash64", "pfbhip_host_alloc", "pfbhip_host_free", "pfbhip_malloc", "pfbhip_free", "pfbhip_memcpy_h2d", "pfbhip_memcpy_d2h", "pfbhip_memcpy_d2d", "pfbhip_memset",
     "pfbhip_synchronize",
     "pfbhip_gridder_create", "pfbhip_gridder_destroy", "pfbhip_gridder_get_info", "pfbhip_gridder_get_binmap",
     "pfbhip_gridder_get_planes",
@@ -69,7 +69,7 @@ SYMBOLS = (
     "pfbhip_gridder_set_weights", "pfbhip_gridder_hessian", "pfbhip_gridder_hessian_dev",
     "pfbhip_gridder_degrid_dev", "pfbhip_gridder_grid_dev", "pfbhip_gridder_profile", "pfbhip_gridder_profile_get",
     "pfbhip_gridder_debug_stamps",
-    "pfbhip_gridder_cg",
+    "pfbhip_gridder_cg", "pfbhip_gridder_cg_dev",
     "pfbhip_r2c_2d", "pfbhip_c2r_2d", "pfbhip_debug_rowfft",
     "pfbhip_psi_create", "pfbhip_psi_destroy", "pfbhip_psi_shape", "pfbhip_psi_dot", "pfbhip_psi_hdot",
     "pfbhip_psi_dot_dev", "pfbhip_psi_hdot_dev", "pfbhip_dual_update", "pfbhip_l21_vtilde_sum_dev",
@@ -145,6 +145,47 @@ def as_c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+_pinned_pool = {}  # nbytes -> [address, ...]: page-locked buffers whose arrays were garbage-collected
+_PINNED_POOL_BYTES = int(os.environ.get("PFBHIP_PINNED_POOL_MB", "4096")) << 20
+_pinned_pooled = [0]
+_PINNED_MIN_BYTES = 1 << 20
+
+
+def _pinned_release(addr, nbytes):
+    if _pinned_pooled[0] + nbytes <= _PINNED_POOL_BYTES:
+        _pinned_pool.setdefault(nbytes, []).append(addr)
+        _pinned_pooled[0] += nbytes
+    else:
+        try:
+            lib().pfbhip_host_free(vp(addr))
+        except Exception:
+            pass
+
+
+def result_empty(shape, dtype):
+    """``np.empty(shape, dtype)`` for an array this package RETURNS (dirty image, visibilities), backed by page-locked host
+    memory so that the device-to-host copy runs at the PCIe rate.  The buffer goes back to a small pool when the array (and
+    every view of it) has been garbage-collected; small arrays are ordinary numpy allocations."""
+    import weakref
+
+    dtype = np.dtype(dtype)
+    shape = tuple(int(s) for s in (shape if np.iterable(shape) else (shape,)))
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes < _PINNED_MIN_BYTES or os.environ.get("PFBHIP_PINNED_RESULTS", "1") == "0":
+        return np.empty(shape, dtype=dtype)
+    free = _pinned_pool.get(nbytes)
+    if free:
+        addr = free.pop()
+        _pinned_pooled[0] -= nbytes
+    else:
+        p = vp()
+        check(lib().pfbhip_host_alloc(ct.byref(p), ct.c_size_t(nbytes)))
+        addr = p.value
+    buf = (ct.c_char * nbytes).from_address(addr)
+    weakref.finalize(buf, _pinned_release, addr, nbytes)  # runs when the last array / view over `buf` is gone
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
 class DeviceArray:
     """A device allocation with numpy-like shape/dtype (host<->device copies are explicit)."""
 
@@ -170,7 +211,7 @@ class DeviceArray:
 
     def download(self, out=None):
         if out is None:
-            out = np.empty(self.shape, dtype=self.dtype)
+            out = result_empty(self.shape, self.dtype)
         assert out.nbytes == self.nbytes and out.flags.c_contiguous
         check(lib().pfbhip_memcpy_d2h(ptr(out), self.ptr, ct.c_size_t(self.nbytes)))
         return out

@@ -686,7 +686,7 @@ struct pfbhip_gridder {
     // row-walk gather (k_degrid_rw): same plans as the record scatter; d_kw: plane weights of every visibility (plan time)
     bool gather_rw = false;
     DevBuf<double> d_kw;
-    float wshare[3] = {1.f / 3, 1.f / 3, 1.f / 3};  // see GroupArgs::wshare (PFBHIP_WSHARE=a,b,c overrides)
+    float wshare[3] = {1.3f / 3, 1.f / 3, 0.7f / 3};  // see GroupArgs::wshare: measured optimum on C2 (equal shares: +7 % scatter time); PFBHIP_WSHARE=a,b,c overrides
     int stamp_mode = 0;  // PFBHIP_STAMP: 1 = record scatter, 2 = row-walk gather
     DevBuf<unsigned long long> d_stamps;  // PFBHIP_STAMP=1: in-kernel phase stamps of the record scatter (8 words per colour work item)
     DevBuf<double2> d_pval;
@@ -1988,6 +1988,22 @@ int pfbhip_gridder_cg(pfbhip_gridder *g, const double *beam_host, double eta, do
         cg.solve([&](const double *in, double *out) { hessian_dev_impl(g, in, beam, eta, wsum, out); }, b.p, x.p, tol,
                  maxit, minit, info);
         PFB_HIP(hipMemcpyAsync(x_host, x.p, size_t(npix) * sizeof(double), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int pfbhip_gridder_cg_dev(pfbhip_gridder *g, const double *beam_dev, double eta, double wsum, const double *rhs_dev, double *x_dev,
+                          int has_x0, double tol, int maxit, int minit, pfbhip_cg_info *info)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && rhs_dev && x_dev, "NULL argument");
+        PFB_REQUIRE(g->weights_bound, "call pfbhip_gridder_set_weights before the CG solve");
+        hipStream_t st = g->stream;
+        const int64_t npix = g->prm.nx * g->prm.ny;
+        if (!has_x0) PFB_HIP(hipMemsetAsync(x_dev, 0, size_t(npix) * sizeof(double), st));
+        DevCG cg(npix, st);
+        cg.solve([&](const double *in, double *out) { hessian_dev_impl(g, in, beam_dev, eta, wsum, out); }, rhs_dev, x_dev, tol,
+                 maxit, minit, info);
         PFB_HIP(hipStreamSynchronize(st));
     });
 }

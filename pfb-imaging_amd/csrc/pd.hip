@@ -18,6 +18,8 @@
 #include <utility>
 #include <vector>
 
+#include <chrono>
+
 #include "common.hpp"
 #include "devcg.hpp"
 #include "pipeline_api.hpp"
@@ -125,6 +127,8 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
         auto blocks = [](size_t n) { return dim3(uint32_t(ceil_div(int64_t(n), 256))); };
         double eps = 1.0;
         int k = 0, status = 1;
+        const auto t_loop0 = std::chrono::steady_clock::now();  // (the stream is idle here: the uploads above were synchronised)
+        PFB_HIP(hipStreamSynchronize(st));
         for (; k < maxit; ++k) {
             for (int64_t b = 0; b < nband; ++b) psi_dot_async(psi, xp + size_t(b) * npix, v + size_t(b) * cube);
             // v <- dual update(vp, Psi^H xp) ; vext <- 2 v - vp
@@ -184,6 +188,8 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
             std::swap(x, xp);  // xp <- x
             std::swap(v, vp);  // vp <- v
         }
+        // (every iteration ends with a stream synchronisation: the wall clock brackets exactly the device work of the loop)
+        const double loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count();
         // after a break x / v hold the last iterate; after maxit the final swap moved them to xp / vp
         if (status != 0) {
             std::swap(x, xp);
@@ -196,6 +202,7 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
             info->iters = status == 0 ? k : maxit - 1;  // the reference reports the loop index k
             info->status = status;
             info->eps = eps;
+            info->loop_ms = loop_ms;
         }
     });
 }

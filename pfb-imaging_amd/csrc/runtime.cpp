@@ -155,6 +155,25 @@ uint64_t pfbhip_hash64(const void *data_host, size_t nbytes)
     return mix(h ^ mix(tail + 0x51ull));
 }
 
+// Page-locked host memory for the RESULT arrays the Python layer hands back (dirty images, visibilities): a device-to-host
+// copy into pageable memory runs at ~12 GB/s on the target host (the runtime stages it through a bounce buffer), into
+// pinned memory at the PCIe rate (~55 GB/s).
+int pfbhip_host_alloc(void **ptr_host, size_t bytes)
+{
+    return guarded([&] {
+        PFB_REQUIRE(ptr_host, "NULL argument");
+        *ptr_host = nullptr;
+        if (bytes) PFB_HIP(hipHostMalloc(ptr_host, bytes, hipHostMallocDefault));
+    });
+}
+
+int pfbhip_host_free(void *ptr_host)
+{
+    return guarded([&] {
+        if (ptr_host) PFB_HIP(hipHostFree(ptr_host));
+    });
+}
+
 int pfbhip_malloc(void **ptr_dev, size_t bytes)
 {
     return guarded([&] {

@@ -202,7 +202,7 @@ class PrimalDual:
             vall[local] = v
             vall = comm.allreduce_sum(vall).reshape(vfull.shape)
         self._v[...] = vall.transpose(0, 1, 3, 2) if transposed else vall
-        self.last = dict(iters=info.iters, status=info.status, eps=info.eps)
+        self.last = dict(iters=info.iters, status=info.status, eps=info.eps, loop_ms=float(info.loop_ms))
         x[...] = xall
         return x
 

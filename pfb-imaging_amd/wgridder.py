@@ -91,13 +91,13 @@ class Gridder:
     # -- operators (host arrays) --------------------------------------------
     def vis2dirty(self, vis, wgt=None):
         vis, wgt = self._vis(vis), self._wgt(wgt)
-        out = np.empty((self.nx, self.ny), dtype=np.float64)
+        out = _lib.result_empty((self.nx, self.ny), np.float64)
         check(lib().pfbhip_gridder_vis2dirty(self._h, ptr(vis), ptr(wgt), ptr(out)))
         return out
 
     def dirty2vis(self, dirty, wgt=None):
         dirty, wgt = self._img(dirty), self._wgt(wgt)
-        out = np.empty((self.nrow, self.nchan), dtype=np.complex128)
+        out = _lib.result_empty((self.nrow, self.nchan), np.complex128)
         check(lib().pfbhip_gridder_dirty2vis(self._h, ptr(dirty), ptr(wgt), ptr(out)))
         return out
 
@@ -106,11 +106,15 @@ class Gridder:
         check(lib().pfbhip_gridder_set_weights(self._h, ptr(wgt)))
         self._weights_token = object()
 
-    def hessian(self, x, beam=None, eta=0.0, wsum=0.0):
-        """beam * R^H W R (beam * x) / wsum + eta x with the weights bound by :meth:`set_weights`."""
+    def hessian(self, x, beam=None, eta=0.0, wsum=0.0, out=None):
+        """beam * R^H W R (beam * x) / wsum + eta x with the weights bound by :meth:`set_weights`; ``out`` (C-contiguous
+        float64, not ``x``) receives the result in place."""
         x = self._img(x, "x")
         beam = None if beam is None else self._img(beam, "beam")
-        out = np.empty_like(x)
+        if out is None:
+            out = _lib.result_empty(x.shape, np.float64)
+        elif out.shape != x.shape or out.dtype != np.float64 or not out.flags.c_contiguous or np.shares_memory(out, x):
+            raise ValueError("out must be a C-contiguous float64 array of the image shape that does not alias x")
         check(lib().pfbhip_gridder_hessian(self._h, ptr(x), ptr(beam), f64(eta or 0.0), f64(wsum or 0.0), ptr(out)))
         return out
 
@@ -135,6 +139,15 @@ class Gridder:
                                       ct.byref(info)))
         self.last_cg = dict(iters=info.iters, status=info.status, eps=info.eps, phi=info.phi)
         return x
+
+    def cg_dev(self, rhs_dev, x_dev, beam_dev=None, eta=0.0, wsum=0.0, has_x0=False, tol=1e-5, maxit=500, minit=100):
+        """The same solve with rhs / x (and beam) resident in HBM (``DeviceArray``); returns the CG info dict."""
+        info = CGInfo()
+        check(lib().pfbhip_gridder_cg_dev(self._h, None if beam_dev is None else beam_dev.ptr, f64(eta or 0.0), f64(wsum or 0.0),
+                                          rhs_dev.ptr, x_dev.ptr, cint(int(bool(has_x0))), f64(tol), cint(maxit), cint(minit),
+                                          ct.byref(info)))
+        self.last_cg = dict(iters=info.iters, status=info.status, eps=info.eps, phi=info.phi)
+        return self.last_cg
 
     def power_method(self, b0, beam=None, eta=0.0, wsum=0.0, tol=1e-5, maxit=250):
         """On-device power iteration on :meth:`hessian` (power_method_numba semantics): returns ``(beta, b)``."""
