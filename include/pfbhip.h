@@ -164,6 +164,8 @@ int pfbhip_gridder_hessian_dev(pfbhip_gridder *g, const double *x_dev, const dou
                                double wsum, double *out_dev);
 /* Device-resident single directions (bench / on-device solvers).  vis_sorted_dev
  * holds nactive complex values in the handle's tile-sorted order. */
+/* vis2dirty with the image left in HBM (row-sharded single band: the partial images are summed over xGMI before one download) */
+int pfbhip_gridder_vis2dirty_dev(pfbhip_gridder *g, const double *vis_host, const double *wgt_host, double *dirty_dev);
 int pfbhip_gridder_degrid_dev(pfbhip_gridder *g, const double *dirty_dev, double *vis_sorted_dev);
 int pfbhip_gridder_grid_dev(pfbhip_gridder *g, const double *vis_sorted_dev, double *dirty_dev);
 
@@ -368,6 +370,13 @@ int pfbhip_comm_create(const uint8_t *id, int nranks, int rank, pfbhip_comm **ou
 int pfbhip_comm_destroy(pfbhip_comm *c);
 int pfbhip_comm_reduce_sum(pfbhip_comm *c, const double *send_dev, double *recv_dev, int64_t count, int root);
 int pfbhip_comm_allreduce_sum(pfbhip_comm *c, const double *send_dev, double *recv_dev, int64_t count);
+/* All-gather of equal blocks (recv = nranks blocks of `count` doubles, block r from rank r): the band pool's cube-level
+ * methods when every rank owns the same number of bands (operators/band_worker.py:239-308). */
+int pfbhip_comm_allgather(pfbhip_comm *c, const double *send_dev, double *recv_dev, int64_t count);
+/* Host-array forms on the communicator's persistent device staging buffers (no allocation per call). */
+int pfbhip_comm_allreduce_sum_host(pfbhip_comm *c, double *inout_host, int64_t count);
+int pfbhip_comm_reduce_sum_host(pfbhip_comm *c, const double *send_host, double *recv_host, int64_t count, int root);
+int pfbhip_comm_allgather_host(pfbhip_comm *c, const double *send_host, double *recv_host, int64_t count);
 int pfbhip_comm_barrier(pfbhip_comm *c);
 
 #ifdef __cplusplus

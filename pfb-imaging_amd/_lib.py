@@ -65,7 +65,7 @@ SYMBOLS = (
     "pfbhip_synchronize",
     "pfbhip_gridder_create", "pfbhip_gridder_destroy", "pfbhip_gridder_get_info", "pfbhip_gridder_get_binmap",
     "pfbhip_gridder_get_planes",
-    "pfbhip_gridder_vis2dirty", "pfbhip_gridder_dirty2vis", "pfbhip_gridder_grid_plane",
+    "pfbhip_gridder_vis2dirty", "pfbhip_gridder_vis2dirty_dev", "pfbhip_gridder_dirty2vis", "pfbhip_gridder_grid_plane",
     "pfbhip_gridder_set_weights", "pfbhip_gridder_hessian", "pfbhip_gridder_hessian_dev",
     "pfbhip_gridder_degrid_dev", "pfbhip_gridder_grid_dev", "pfbhip_gridder_profile", "pfbhip_gridder_profile_get",
     "pfbhip_gridder_debug_stamps",
@@ -80,7 +80,8 @@ SYMBOLS = (
     "pfbhip_uvcell_index", "pfbhip_compute_counts", "pfbhip_counts_divide", "pfbhip_box_sum_counts",
     "pfbhip_filter_extreme_counts", "pfbhip_imaging_weights",
     "pfbhip_comm_unique_id", "pfbhip_comm_create", "pfbhip_comm_destroy", "pfbhip_comm_reduce_sum",
-    "pfbhip_comm_allreduce_sum", "pfbhip_comm_barrier",
+    "pfbhip_comm_allreduce_sum", "pfbhip_comm_allgather", "pfbhip_comm_allreduce_sum_host", "pfbhip_comm_reduce_sum_host",
+    "pfbhip_comm_allgather_host", "pfbhip_comm_barrier",
 )
 
 _lib = None

@@ -25,6 +25,8 @@ struct pfbhip_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     int nranks = 1, rank = 0;
+    // persistent device staging of the host-array collectives (grow-only: no hipMalloc per call)
+    pfbhip::DevBuf<double> stage_a, stage_b;
     ~pfbhip_comm()
     {
         if (comm) ncclCommDestroy(comm);
@@ -88,6 +90,62 @@ int pfbhip_comm_allreduce_sum(pfbhip_comm *c, const double *send_dev, double *re
     return guarded([&] {
         PFB_REQUIRE(c && send_dev && recv_dev && count >= 0, "NULL argument");
         PFB_NCCL(ncclAllReduce(send_dev, recv_dev, size_t(count), ncclDouble, ncclSum, c->comm, c->stream));
+        PFB_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int pfbhip_comm_allgather(pfbhip_comm *c, const double *send_dev, double *recv_dev, int64_t count)
+{
+    return guarded([&] {
+        PFB_REQUIRE(c && send_dev && recv_dev && count >= 0, "NULL argument");
+        PFB_NCCL(ncclAllGather(send_dev, recv_dev, size_t(count), ncclDouble, c->comm, c->stream));
+        PFB_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+// Host-array forms (the cube-level methods of the band pool return numpy arrays): upload -> collective on the persistent
+// staging buffers -> download, all on the communicator's stream.
+int pfbhip_comm_allreduce_sum_host(pfbhip_comm *c, double *inout_host, int64_t count)
+{
+    return guarded([&] {
+        PFB_REQUIRE(c && inout_host && count >= 0, "NULL argument");
+        if (count == 0) return;
+        c->stage_a.ensure(size_t(count));
+        PFB_HIP(hipMemcpyAsync(c->stage_a.p, inout_host, size_t(count) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PFB_NCCL(ncclAllReduce(c->stage_a.p, c->stage_a.p, size_t(count), ncclDouble, ncclSum, c->comm, c->stream));
+        PFB_HIP(hipMemcpyAsync(inout_host, c->stage_a.p, size_t(count) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PFB_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int pfbhip_comm_reduce_sum_host(pfbhip_comm *c, const double *send_host, double *recv_host, int64_t count, int root)
+{
+    return guarded([&] {
+        PFB_REQUIRE(c && send_host && count >= 0, "NULL argument");
+        PFB_REQUIRE(root >= 0 && root < c->nranks, "bad root %d", root);
+        PFB_REQUIRE(recv_host || c->rank != root, "root needs a receive buffer");
+        if (count == 0) return;
+        c->stage_a.ensure(size_t(count));
+        PFB_HIP(hipMemcpyAsync(c->stage_a.p, send_host, size_t(count) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PFB_NCCL(ncclReduce(c->stage_a.p, c->stage_a.p, size_t(count), ncclDouble, ncclSum, root, c->comm, c->stream));
+        if (c->rank == root)
+            PFB_HIP(hipMemcpyAsync(recv_host, c->stage_a.p, size_t(count) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PFB_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+// recv_host holds nranks blocks of `count` doubles, block r = rank r's send_host
+int pfbhip_comm_allgather_host(pfbhip_comm *c, const double *send_host, double *recv_host, int64_t count)
+{
+    return guarded([&] {
+        PFB_REQUIRE(c && send_host && recv_host && count >= 0, "NULL argument");
+        if (count == 0) return;
+        c->stage_a.ensure(size_t(count));
+        c->stage_b.ensure(size_t(count) * size_t(c->nranks));
+        PFB_HIP(hipMemcpyAsync(c->stage_a.p, send_host, size_t(count) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PFB_NCCL(ncclAllGather(c->stage_a.p, c->stage_b.p, size_t(count), ncclDouble, c->comm, c->stream));
+        PFB_HIP(hipMemcpyAsync(recv_host, c->stage_b.p, size_t(count) * size_t(c->nranks) * sizeof(double), hipMemcpyDeviceToHost,
+                               c->stream));
         PFB_HIP(hipStreamSynchronize(c->stream));
     });
 }

@@ -1812,6 +1812,22 @@ int pfbhip_gridder_vis2dirty(pfbhip_gridder *g, const double *vis_host, const do
     });
 }
 
+int pfbhip_gridder_vis2dirty_dev(pfbhip_gridder *g, const double *vis_host, const double *wgt_host, double *dirty_dev)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && dirty_dev && (vis_host || g->nvis == 0), "NULL argument");
+        hipStream_t st = g->stream;
+        g->upload_vis_wgt(vis_host, wgt_host);
+        if (g->info.nactive)
+            hipLaunchKernelGGL(k_permute_in, blocks1d(g->info.nactive), dim3(256), 0, st, g->map, g->d_src.p,
+                               g->info.nactive, g->d_vis.p, wgt_host ? g->d_wgt.p : nullptr, int(g->shifting),
+                               g->info.lshift, g->info.mshift, g->info.nshift, g->d_sval.p);
+        PFB_HIP(hipGetLastError());
+        g->grid_and_finalize(g->d_sval.p, nullptr, 1.0, 0.0, nullptr, dirty_dev);
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
 int pfbhip_gridder_grid_plane(pfbhip_gridder *g, const double *vis_host, const double *wgt_host, int64_t plane,
                               double *grid_host)
 {

@@ -152,9 +152,21 @@ class BandWorkerPool:
         return {b: getattr(self.workers[b], method)(*per_band_args[b]) for b in self.local}
 
     def _exchange(self, cube):
-        """Every band of ``cube`` was filled by exactly one rank (zeros elsewhere): sum = gather."""
+        """Every band of ``cube`` was filled by exactly one rank (zeros elsewhere).  When every rank owns the same number of
+        bands the exchange is an ALL-GATHER of the local bands (each byte crosses xGMI once, (N-1)/N of the cube per rank);
+        otherwise the zero-padded cube is all-reduced (sum = gather).  Both run on the communicator's persistent device
+        staging buffers."""
         if self.comm is None or self.comm.world_size == 1:
             return cube
+        world = self.comm.world_size
+        if self.nband % world == 0 and hasattr(self.comm, "allgather"):
+            nloc = self.nband // world
+            mine = np.ascontiguousarray(cube[self.local])            # bands rank, rank + N, ... (b % N == rank)
+            got = self.comm.allgather(mine)                           # (world, nloc, ...)
+            out = np.empty_like(cube)
+            for r in range(world):
+                out[r::world] = got[r][:nloc]
+            return out
         return self.comm.allreduce_sum(cube).reshape(cube.shape)
 
     # --- band loading ---

@@ -105,14 +105,9 @@ class BandComm:
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         if self.world_size == 1:
             return arr
-        if self.transport == "rccl":
-            d = DeviceArray.from_host(arr)
-            r = DeviceArray(arr.shape, np.float64) if self.rank == root else None
-            self.reduce_sum_dev(d, r, root)
-            out = r.download() if r is not None else None
-            d.free()
-            if r is not None:
-                r.free()
+        if self.transport == "rccl":  # upload -> ncclReduce -> download on the communicator's persistent staging buffer
+            out = _lib.result_empty(arr.shape, np.float64) if self.rank == root else None
+            check(lib().pfbhip_comm_reduce_sum_host(self._h, ptr(arr), ptr(out), i64(arr.size), cint(root)))
             return out
         import torch
 
@@ -125,16 +120,29 @@ class BandComm:
         if self.world_size == 1:
             return arr
         if self.transport == "rccl":
-            d = DeviceArray.from_host(arr)
-            self.allreduce_sum_dev(d, d)
-            out = d.download()
-            d.free()
+            out = arr.copy()
+            check(lib().pfbhip_comm_allreduce_sum_host(self._h, ptr(out), i64(out.size)))
             return out
         import torch
 
         t = torch.from_numpy(arr.copy())
         self._dist.all_reduce(t)
         return t.numpy()
+
+    def allgather(self, arr):
+        """Blocks of equal shape from every rank, stacked along a new leading axis (rank order)."""
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.world_size == 1:
+            return arr[None]
+        if self.transport == "rccl":
+            out = _lib.result_empty((self.world_size,) + arr.shape, np.float64)
+            check(lib().pfbhip_comm_allgather_host(self._h, ptr(arr), ptr(out), i64(arr.size)))
+            return out
+        import torch
+
+        parts = [torch.empty(arr.shape, dtype=torch.float64) for _ in range(self.world_size)]
+        self._dist.all_gather(parts, torch.from_numpy(arr.copy()))
+        return np.stack([p.numpy() for p in parts])
 
     def max_over_ranks(self, value):
         if self.world_size == 1:
@@ -196,8 +204,26 @@ class RowShardedGridder:
     def _rows(self, a):
         return None if a is None else a[self.r0:self.r1]
 
+    def _device_exchange(self):
+        """True when the partial images can stay in HBM between the local gridder and the collective."""
+        return self.comm.world_size > 1 and self.comm.transport == "rccl" and hasattr(self.local, "vis2dirty_dev")
+
+    def _img_buffers(self):
+        if getattr(self, "_dbuf", None) is None:
+            shape = (self.local.nx, self.local.ny)
+            self._dbuf = (DeviceArray(shape, np.float64), DeviceArray(shape, np.float64))
+        return self._dbuf
+
     def vis2dirty(self, vis, wgt=None, root=None):
         """Sum over ranks of the partial dirty images: on every rank (``root=None``) or on ``root`` only."""
+        if self._device_exchange():  # partial image -> xGMI sum -> ONE download, on persistent device buffers
+            part, _ = self._img_buffers()
+            self.local.vis2dirty_dev(self._rows(vis), self._rows(wgt), part)
+            if root is None:
+                self.comm.allreduce_sum_dev(part, part)
+                return part.download()
+            self.comm.reduce_sum_dev(part, part if self.comm.rank == root else None, root=root)
+            return part.download() if self.comm.rank == root else None
         part = self.local.vis2dirty(self._rows(vis), self._rows(wgt))
         if root is None:
             return self.comm.allreduce_sum(part).reshape(part.shape)
@@ -213,11 +239,26 @@ class RowShardedGridder:
 
     def hessian(self, x, beam=None, eta=0.0, wsum=0.0):
         """beam R^H W R (beam x) / wsum + eta x over ALL rows: local partials + one all-reduce."""
-        part = self.local.hessian(x, beam=beam, eta=0.0, wsum=wsum)
-        out = self.comm.allreduce_sum(part).reshape(part.shape)
+        if self._device_exchange():
+            xd, od = self._img_buffers()
+            xd.upload(x)
+            bd = None
+            if beam is not None:
+                bd = DeviceArray.from_host(np.ascontiguousarray(beam, dtype=np.float64))
+            self.local.hessian_dev(xd, od, beam_dev=bd, eta=0.0, wsum=wsum)
+            self.comm.allreduce_sum_dev(od, od)
+            out = od.download()
+            if bd is not None:
+                bd.free()
+        else:
+            part = self.local.hessian(x, beam=beam, eta=0.0, wsum=wsum)
+            out = self.comm.allreduce_sum(part).reshape(part.shape)
         if eta:
             out = out + eta * x
         return out
 
     def close(self):
+        for d in getattr(self, "_dbuf", None) or ():
+            d.free()
+        self._dbuf = None
         self.local.close()

@@ -95,6 +95,11 @@ class Gridder:
         check(lib().pfbhip_gridder_vis2dirty(self._h, ptr(vis), ptr(wgt), ptr(out)))
         return out
 
+    def vis2dirty_dev(self, vis, wgt, out_dev):
+        """:meth:`vis2dirty` with the image left in HBM (``out_dev``: DeviceArray of the image shape)."""
+        vis, wgt = self._vis(vis), self._wgt(wgt)
+        check(lib().pfbhip_gridder_vis2dirty_dev(self._h, ptr(vis), ptr(wgt), out_dev.ptr))
+
     def dirty2vis(self, dirty, wgt=None):
         dirty, wgt = self._img(dirty), self._wgt(wgt)
         out = _lib.result_empty((self.nrow, self.nchan), np.complex128)

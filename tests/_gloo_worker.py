@@ -127,6 +127,12 @@ def main():
     dual_update_bands(vp, v, 0.8, 1.7, wgt, comm=comm, bands=pool.local, phases=(vtilde_sum, scale))
     np.testing.assert_allclose(v, opsi.dual_update(vp, alpha.copy(), 0.8, 1.7, wgt), rtol=0, atol=1e-13)
 
+    # as many bands per rank everywhere (nband % world == 0): the cube exchange is an all-gather of the local bands
+    pool4 = BandWorkerPool(4, comm=comm, worker_cls=FakeWorker)
+    pool4.init_hess(diag[:4], nx, ny, 2 * nx, 2 * ny, np.full(4, 0.25), [None] * 4)
+    np.testing.assert_allclose(pool4.hess_dot(x[:4]), np.stack([(diag[b] + 0.25) * x[b] for b in range(4)]), rtol=1e-14)
+    assert np.array_equal(comm.allgather(np.full((2, 3), float(comm.rank))), np.stack([np.zeros((2, 3)), np.ones((2, 3))]))
+
     # fewer bands than ranks (e.g. 4 bands on 8 GPUs): rank 1 holds no band, takes part in every collective, and the
     # choice between the device-resident and the generic primal-dual / power-method loop is made by ALL ranks together
     from pfb_imaging_amd.operators.hessian import HessTreeRay
