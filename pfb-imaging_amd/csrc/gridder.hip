@@ -649,12 +649,7 @@ struct pfbhip_gridder {
     template <int W, int KP>
     void launch_grid_mp_wk(const GroupArgs &ga, const double2 *sval)
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_mp<W, KP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp_max<W>())));
-            attr_set = true;
-        }
+        allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_mp<W, KP>), int(lds_bytes_mp_max<W>()));
         hipLaunchKernelGGL((k_grid_mp<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga, sval,
                            grid_cur);
     }
@@ -666,12 +661,7 @@ struct pfbhip_gridder {
     template <int W, int KP>
     void launch_grid_blk_wk(const GroupArgs &ga, const double2 *sval)
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_blk<W, KP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_blk<W, KP>), 160 * 1024);
         const size_t lds = lds_bytes_blk<W, KP>();
         PFB_REQUIRE(lds <= size_t(160) * 1024, "block scatter needs %zu bytes of LDS", lds);
         hipLaunchKernelGGL((k_grid_blk<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, sval, grid_cur);
@@ -693,12 +683,7 @@ struct pfbhip_gridder {
     template <int W, int KP>
     void launch_grid_rec_wk(const GroupArgs &ga)
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_rec<W, KP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_rec<W, KP>), 160 * 1024);
         const size_t lds = lds_bytes_blk<W, KP>();
         PFB_REQUIRE(lds <= size_t(160) * 1024, "record scatter needs %zu bytes of LDS", lds);
         hipLaunchKernelGGL((k_grid_rec<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, d_rec.p, d_pval.p,
@@ -755,24 +740,14 @@ struct pfbhip_gridder {
     template <int W, int KP>
     void launch_degrid_mp_wk(const GroupArgs &ga, double2 *sacc)
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_degrid_mp<W, KP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes_mp_max<W>())));
-            attr_set = true;
-        }
+        allow_dynamic_lds(reinterpret_cast<const void *>(&k_degrid_mp<W, KP>), int(lds_bytes_mp_max<W>()));
         hipLaunchKernelGGL((k_degrid_mp<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga,
                            grid_cur, sacc, want_pval ? d_swgt.p : nullptr, want_pval ? d_pval.p : nullptr);
     }
     template <int W, int KP>
     void launch_degrid_rw_wk(const GroupArgs &ga, double2 *sacc)
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_degrid_rw<W, KP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        allow_dynamic_lds(reinterpret_cast<const void *>(&k_degrid_rw<W, KP>), 160 * 1024);
         const size_t lds = size_t(KP) * RW_LS * RW_LS * sizeof(double2);
         GroupArgs gs = ga;
         if (stamp_mode == 2 && d_stamps.p != nullptr) gs.dbg = d_stamps.p;

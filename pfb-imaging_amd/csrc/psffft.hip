@@ -260,11 +260,9 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_rows_inv(const 
 // ---- host side -------------------------------------------------------------------------------------
 
 template <class Kern>
-static void psf_allow_lds(Kern kern, bool *done)
+static void psf_allow_lds(Kern kern, bool *)
 {
-    if (*done) return;
-    PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    *done = true;
+    allow_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024);  // per (device, kernel)
 }
 
 bool PsfFFT::init(int64_t nx_, int64_t ny_, int64_t nxp_, int64_t nyp_)

@@ -37,14 +37,11 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_plain(const 
     rf_row<S>(tw, ld, st, INV, rf_lds);
 }
 
-// LDS beyond 64 KiB needs the opt-in attribute, once per kernel instantiation
+// LDS beyond 64 KiB needs the opt-in attribute, per (device, kernel): see allow_dynamic_lds()
 template <class Kern>
-static void rf_allow_lds(Kern kern, bool *done)
+static void rf_allow_lds(Kern kern, bool *)
 {
-    if (*done) return;
-    PFB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    *done = true;
+    allow_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
 }
 
 bool RowFFT::init(int64_t N)

@@ -6,6 +6,8 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <set>
+#include <utility>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,6 +27,18 @@ void rocfft_setup_once()
 }
 
 static std::atomic<int> g_pool_size{1};
+
+static std::mutex g_lds_mutex;
+static std::set<std::pair<int, const void *>> g_lds_done;
+void allow_dynamic_lds(const void *kernel, int bytes)
+{
+    int dev = 0;
+    PFB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_lds_mutex);
+    if (g_lds_done.count({dev, kernel})) return;
+    PFB_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    g_lds_done.insert({dev, kernel});
+}
 
 }  // namespace pfbhip
 

@@ -45,26 +45,24 @@ class _BandWorkerImpl:
             self._resid = None
 
     def load_band(self, store_url, node_name):
-        """Read this band's inputs from the ``.dt`` store (band_worker.py:61-106).  Needs the
-        reference's I/O stack (xarray + zarr); the arrays then stay pinned on this worker's GPU."""
+        """Read this band's inputs from the ``.dt`` store (band_worker.py:61-106): ``store_url`` is a store path (opened
+        with xarray, as the reference does) or an already-open store / in-memory mapping (see ``pfb_imaging_amd.store``).
+        Every array is decoded straight into page-locked memory and stays with this worker; the device plans built from
+        them upload at the PCIe rate."""
         import gc
 
+        from ..store import load_band as _load
+
         try:
-            import xarray as xr
-        except ImportError as e:  # pragma: no cover - I/O stack is not part of this package
-            raise ImportError("load_band needs xarray/zarr (the reference's storage layer); "
-                              "use set_band() with in-memory arrays instead") from e
-        try:
-            band = xr.open_datatree(store_url, engine="zarr", chunks=None)[node_name]
-            dirty = band.ds.DIRTY.values
-            parts, hess_parts = [], []
-            for cname in sorted(band.children):
-                child = band[cname].ds
-                pds = child[["UVW", "WEIGHT", "MASK", "FREQ", "BEAM"]].load()
-                pds.attrs.update(child.attrs)
-                hess_parts.append({"psfhat": np.abs(child.PSFHAT.values), "beam": pds.BEAM.values,
-                                   "wsum": np.asarray(child.attrs["wsum"])})
-                parts.append(pds)
+            store = store_url
+            if isinstance(store_url, (str, bytes)):
+                try:
+                    import xarray as xr
+                except ImportError as e:  # pragma: no cover - the storage stack is not part of this package
+                    raise ImportError("opening a store path needs xarray + zarr (the reference's storage layer); pass an "
+                                      "open store / mapping, or use set_band() with in-memory arrays") from e
+                store = xr.open_datatree(store_url, engine="zarr", chunks=None)
+            dirty, parts, hess_parts = _load(store, node_name)
             self.set_band(dirty, parts, hess_parts)
         finally:
             gc.collect()
