@@ -93,7 +93,7 @@ def test_band_worker_loads_from_store_into_pinned_buffers():
     model = rng.standard_normal((1, nx, ny))
     res = w.residual(model, cell, 1e-7, True, True)
     ref = residual_from_partitions(prod["DIRTY"], [dict(part, WEIGHT=prod["WEIGHT"], BEAM=prod["BEAM"])], model, cell)
-    assert np.linalg.norm(res - ref) / np.linalg.norm(ref) < 1e-12
+    assert np.linalg.norm(res - ref) / np.linalg.norm(ref) < 1e-10   # (same arithmetic; the scatter's LDS atomics reorder sums)
     w.init_hess(None, nx, ny, 2 * nx, 2 * ny, 0.1, None)
     h = w.hess_dot(model)
     assert h.shape == model.shape and np.isfinite(h).all()
