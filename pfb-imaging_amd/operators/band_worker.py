@@ -95,7 +95,7 @@ class _BandWorkerImpl:
                 self._resid.close()
             self._resid = PartitionResidual(self._parts, nx, ny, cell_rad, epsilon=epsilon, do_wgridding=do_wgridding)
             self._resid_key = key
-        if not np.any(model):
+        if not _lib.any_nonzero(model):
             return self._dirty - np.zeros_like(self._dirty)
         return self._dirty - self._resid.convim(model)
 

@@ -13,6 +13,7 @@ xarray-like objects (``part.UVW.values``, ``part.attrs``) or as plain dicts of n
 
 import numpy as np
 
+from .. import _lib
 from .. import fft as _fft
 from ..misc import resize_thread_pool
 from ..utils.weighting import counts_to_weights, imaging_weights
@@ -204,7 +205,7 @@ def residual_from_partitions(dirty, parts, model, cell_rad, nthreads=1, epsilon=
     """``dirty - sum_p R_p^H W_p R_p (beam_p * model)`` (gridder.py:926-1016)."""
     resize_thread_pool(nthreads)
     ncorr, nx, ny = dirty.shape
-    if not np.any(model):
+    if not _lib.any_nonzero(model):
         # degridding a zero model gives zero visibilities; skip the device entirely
         return dirty - np.zeros_like(dirty)
     state = PartitionResidual(parts, nx, ny, cell_rad, epsilon=epsilon, do_wgridding=do_wgridding)

@@ -15,6 +15,7 @@ scratch lives on the device.
 
 import numpy as np
 
+from .. import _lib
 from ..psfconv import PsfConv, cached_plan, cached_psf_slot
 from ..wgridder import _get_gridder
 
@@ -45,7 +46,7 @@ def hessian_slice(x, xout=None, uvw=None, weight=None, vis_mask=None, freq=None,
     ``x0, y0, flip_*`` must follow ``wgridder_conventions``.  Returns zeros without touching the
     GPU when ``x`` is identically zero (hessian.py:47-48).  ``xout`` is filled in place if given.
     """
-    if not x.any():
+    if not _lib.any_nonzero(x):
         return np.zeros_like(x)
     nx, ny = x.shape
     # hessian_slice calls ducc0 with its default oversampling bounds (no sigma_min/sigma_max)

@@ -239,7 +239,7 @@ class PrimalDual:
             x[...] = xp - self.tau * xout
             if self.primal_prox is not None:
                 self.primal_prox(x)
-            if x.any():
+            if _lib.any_nonzero(x):
                 eps = float(np.sqrt(((x - xp) ** 2).sum() / max((x**2).sum(), 1e-12)))
             else:
                 eps = 1.0
@@ -383,7 +383,7 @@ def _cg_host(aop, b, x0, precond, tol, maxit, minit, verbosity, report_freq, ret
     x = x0
     r = aop(x) - b
     y = precond(r)
-    if not np.any(y):
+    if not _lib.any_nonzero(y):
         print("Initial residual is zero")
         return (x, r) if return_resid else x
     p = -y
@@ -478,7 +478,7 @@ def pcg_numba(aop, b, x0=None, precond=None, tol=1e-5, maxit=500, minit=100, ver
         x0 = np.zeros(np.shape(b), dtype=np.asarray(b).dtype)
     target = _device_cg_target(aop) if precond is None else None
     if target is not None and np.asarray(b).ndim == 2:
-        if not np.any(b) and not np.any(x0):
+        if not _lib.any_nonzero(b) and not _lib.any_nonzero(x0):
             print("Initial residual is zero")
             return (x0, np.zeros_like(x0)) if return_resid else x0
         return _cg_device(target, aop, b, x0, tol, maxit, minit, verbosity, return_resid)

@@ -17,7 +17,7 @@ import sys
 
 STAGE_OF = [
     ("k_grid", "grid"), ("k_degrid", "degrid"), ("k_fused_fft_crop", "fft_crop"), ("k_fused_pad_fft", "pad_fft"),
-    ("k_rowfft_plain", "fft_rows"), ("fft_", "fft_rows"), ("transpose_", "fft_rows"),
+    ("k_rowfft", "fft_rows"), ("fft_", "fft_rows"), ("transpose_", "fft_rows"),
     ("k_pad_screen", "pad"), ("k_b2a", "pad"), ("k_crop_screen", "crop"), ("k_a2b", "crop"),
 ]
 
