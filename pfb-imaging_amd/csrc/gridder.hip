@@ -967,7 +967,7 @@ struct pfbhip_gridder {
                 if (tfft) {
                     timer.begin(2);
                     rowfft_b2a(rowfft_v.pl, d_gridB.p + size_t(k) * bstride, grid_cur + size_t(k) * plane_stride, d_rowmap.p,
-                               int(occ_rows), geom.bpitch, int(prm.ny), size_t(geom.apitch), stream);
+                               int(occ_rows), geom.bpitch, int(prm.ny), size_t(geom.apitch), fgeom.tpitch, stream);
                     timer.end();
                     continue;
                 }
@@ -1589,6 +1589,18 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         g->fgeom.bpitch = g->geom.bpitch;
     }
     g->bstride = size_t(prm.ny) * size_t(g->geom.bpitch);
+    // Degridding side of the transposing first-axis FFT: the fused pad kernel stores Bt[u][y] (scattered 16-byte stores that
+    // meet in L2, as on the gridding side) and the first-axis transform of row u reads its row of Bt contiguously -- a
+    // 16-byte GATHER in that transform's load phase cost 0.3 ms per plane at C2, scattered stores cost 0.1.  The pitch is
+    // kept off the power of two for the same reason as bpitch (PFBHIP_TPAD elements, multiple of 8 = whole lines; 0 = off).
+    g->fgeom.tpitch = 0;
+    {
+        const char *tenv = std::getenv("PFBHIP_TPAD");
+        const int tpad = tenv != nullptr ? std::atoi(tenv) : 40;
+        if (g->fused && g->rowfft_v.ok && !g->rowfft_v.pl.doubled && g->rowfft_u.ok && !g->rowfft_u.pl.doubled && tpad > 0)
+            g->fgeom.tpitch = int(prm.ny) + ((tpad + 7) / 8) * 8;
+    }
+    g->bstride = std::max(g->bstride, size_t(info.nu) * size_t(g->fgeom.tpitch));
     g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
     g->d_accT.alloc(size_t(npix));
 
@@ -1675,6 +1687,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             PFB_HIP(hipMemcpyAsync(g->d_rowmap.p, map.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
             PFB_HIP(hipStreamSynchronize(st));
         }
+        if (!g->tfft) g->fgeom.tpitch = 0;  // (the tile-transpose kernels read B[y][u])
         info.fft_mode |= g->tfft ? 8 : 0;
     }
     if (any_rocfft) {

@@ -22,7 +22,7 @@ namespace pfbhip {
 // (32 complex per thread at 16384 points -- 512 threads, 256 VGPRs -- was tried against the 1024-thread /
 // 128-VGPR layout and its 35-120 spilled registers in these fused kernels: it spills more.)
 template <int L, int K>
-using PsfShape = RfShape<L, K>;
+using PsfShape = RfShape<L, K, true, 0, false>;  // (both components in LDS: see the hand-over below)
 
 // out (cols, rows) = in (rows, cols)^T, 32 x 32 tiles through LDS
 template <class T>

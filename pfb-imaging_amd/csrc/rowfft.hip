@@ -151,16 +151,35 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_a2b(const do
     rf_row<S>(tw, ld, st, true, rf_lds);
 }
 
-template <class S>
+// Row u of Bt (tpitch elements per row, written by the fused pad kernel with the transpose in ITS stores): contiguous loads.
+struct PadRowLoad {
+    const double2 *row;
+    int ny, nv, hy;
+    __device__ __forceinline__ double2 operator()(int v, int) const
+    {
+        int y = -1;
+        if (v < ny - hy) y = v + hy;
+        else if (v >= nv - hy) y = v - (nv - hy);
+        return y >= 0 ? row[y] : make_double2(0.0, 0.0);
+    }
+};
+
+template <class S, bool TR>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_b2a(const double2 *tw, const double2 *B, double2 *A,
-                                                                          const int *rowmap, int nrows, int nu, int ny, size_t apitch)
+                                                                          const int *rowmap, int nrows, int nu, int ny, size_t apitch,
+                                                                          int tpitch)
 {
     extern __shared__ double rf_lds[];
     if (int(blockIdx.x) >= nrows) return;
     const int u = rowmap[blockIdx.x];
-    PadTLoad ld{B, u, nu, ny, S::N, ny / 2};
     PlainStore st{A + size_t(u) * apitch};
-    rf_row<S>(tw, ld, st, false, rf_lds);
+    if constexpr (TR) {
+        PadRowLoad ld{B + size_t(u) * size_t(tpitch), ny, S::N, ny / 2};
+        rf_row<S>(tw, ld, st, false, rf_lds);
+    } else {
+        PadTLoad ld{B, u, nu, ny, S::N, ny / 2};
+        rf_row<S>(tw, ld, st, false, rf_lds);
+    }
 }
 
 template <class S>
@@ -174,12 +193,18 @@ static void launch_a2b(const RowFFTPlan &pl, const double2 *A, double2 *B, const
 }
 template <class S>
 static void launch_b2a(const RowFFTPlan &pl, const double2 *B, double2 *A, const int *rowmap, int nrows, int nu, int ny,
-                       size_t apitch, hipStream_t stream)
+                       size_t apitch, int tpitch, hipStream_t stream)
 {
-    static bool attr = false;
-    rf_allow_lds(&k_rowfft_b2a<S>, &attr);
-    hipLaunchKernelGGL((k_rowfft_b2a<S>), dim3(uint32_t(nrows)), dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A,
-                       rowmap, nrows, nu, ny, apitch);
+    static bool attr = false, attr_t = false;
+    if (tpitch > 0) {
+        rf_allow_lds(&k_rowfft_b2a<S, true>, &attr_t);
+        hipLaunchKernelGGL((k_rowfft_b2a<S, true>), dim3(uint32_t(nrows)), dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A,
+                           rowmap, nrows, nu, ny, apitch, tpitch);
+        return;
+    }
+    rf_allow_lds(&k_rowfft_b2a<S, false>, &attr);
+    hipLaunchKernelGGL((k_rowfft_b2a<S, false>), dim3(uint32_t(nrows)), dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A,
+                       rowmap, nrows, nu, ny, apitch, 0);
 }
 
 void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, const int *rowmap_dev, int nrows, int nu, int ny,
@@ -197,12 +222,12 @@ void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, cons
 }
 
 void rowfft_b2a(const RowFFTPlan &pl, const double2 *B_dev, double2 *A_dev, const int *rowmap_dev, int nrows, int nu, int ny,
-                size_t apitch, hipStream_t stream)
+                size_t apitch, int tpitch, hipStream_t stream)
 {
     PFB_REQUIRE(!pl.doubled, "transposing row FFT: doubled shapes are not supported");
     switch (pl.N) {
 #define RF_X(L, K)                                                                       \
-    case (L << K): launch_b2a<RfShape<L, K>>(pl, B_dev, A_dev, rowmap_dev, nrows, nu, ny, apitch, stream); break;
+    case (L << K): launch_b2a<RfShape<L, K>>(pl, B_dev, A_dev, rowmap_dev, nrows, nu, ny, apitch, tpitch, stream); break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);
@@ -365,7 +390,13 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
 {
     extern __shared__ double rf_lds[];
     double *lrow = lds_row ? rf_lds + S::LDS_BYTES / sizeof(double) : nullptr;
-    const int y = blockIdx.x;
+    int y = blockIdx.x;
+    if (g.tpitch > 0 && y < (g.ny & ~63)) {
+        // transposed stores (below): the 8 rows y whose 16-byte pieces make up one 128-byte line of Bt go to 8 workgroups of
+        // ONE XCD (block ids equal mod 8) inside the same 64 block ids, so that the line leaves that XCD's L2 whole
+        const int r = y & 63;
+        y = (y & ~63) + (r & 7) * 8 + (r >> 3);
+    }
     uint32_t omask = 0;  // occupancy of the thread's output columns
 #pragma unroll
     for (int e = 0; e < S::E; ++e) omask |= (occ[S::out_pos(int(threadIdx.x), e) >> 5] ? 1u : 0u) << e;
@@ -383,10 +414,17 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
         int t;
         rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
         rf_opaque(t);
-        double2 *brow = B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch);
+        if (g.tpitch > 0) {  // Bt[u][y]: the first-axis transform of row u then reads contiguously (k_rowfft_b2a<S, true>)
+            double2 *bcol = B + size_t(k) * bstride + size_t(y);
 #pragma unroll
-        for (int e = 0; e < S::E; ++e)
-            if ((omask >> e) & 1u) brow[S::out_pos(t, e)] = make_double2(re[e], im[e]);
+            for (int e = 0; e < S::E; ++e)
+                if ((omask >> e) & 1u) bcol[size_t(S::out_pos(t, e)) * size_t(g.tpitch)] = make_double2(re[e], im[e]);
+        } else {
+            double2 *brow = B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch);
+#pragma unroll
+            for (int e = 0; e < S::E; ++e)
+                if ((omask >> e) & 1u) brow[S::out_pos(t, e)] = make_double2(re[e], im[e]);
+        }
     }
 }
 
@@ -773,6 +811,43 @@ void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, 
 
 using namespace pfbhip;
 
+// Diagnostic: the plain row transform with its global loads (MODE & 1) and / or stores (MODE & 2) taken out -- what is left
+// of the row time tells how much of it is the passes themselves.  PFBHIP_RF_MODE selects it in pfbhip_debug_rowfft's timing.
+template <int MODE>
+struct DbgLoad {
+    const double2 *row;
+    __device__ __forceinline__ double2 operator()(int i, int) const
+    {
+        return (MODE & 1) ? make_double2(double(i), 1.0) : row[i];
+    }
+};
+template <int MODE>
+struct DbgStore {
+    double2 *row;
+    __device__ __forceinline__ void operator()(int i, double2 v) const
+    {
+        if (!(MODE & 2) || v.x == 1.2345e300) row[i] = v;
+    }
+};
+template <class S, int MODE>
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_dbg(const double2 *tw, double2 *data, int nrows, size_t pitch)
+{
+    extern __shared__ double rf_lds[];
+    const int row = blockIdx.x;
+    if (row >= nrows) return;
+    DbgLoad<MODE> ld{data + size_t(row) * pitch};
+    DbgStore<MODE> st{data + size_t(row) * pitch};
+    rf_row<S>(tw, ld, st, true, rf_lds);
+}
+template <class S, int MODE>
+static void launch_dbg(const RowFFTPlan &pl, double2 *d, int nrows, size_t pitch)
+{
+    static bool attr = false;
+    rf_allow_lds(&k_rowfft_dbg<S, MODE>, &attr);
+    hipLaunchKernelGGL((k_rowfft_dbg<S, MODE>), dim3(uint32_t(nrows)), dim3(S::T), size_t(S::LDS_BYTES), nullptr, pl.twiddle, d,
+                       nrows, pitch);
+}
+
 extern "C" {
 
 // Debug / benchmark entry: in-place batched row transform of (nrows, n) complex doubles on the host.
@@ -795,7 +870,18 @@ int pfbhip_debug_rowfft(double *data_host, int64_t n, int64_t nrows, int inverse
             PFB_HIP(hipMemcpy(s.p, d.p, tot * sizeof(double2), hipMemcpyDeviceToDevice));
             rowfft_plain(pl, s.p, int(nrows), inverse != 0, nullptr);
             PFB_HIP(hipEventRecord(a, nullptr));
-            for (int r = 0; r < reps; ++r) rowfft_plain(pl, s.p, int(nrows), inverse != 0, nullptr);
+            const char *dm = std::getenv("PFBHIP_RF_MODE");
+            if (dm != nullptr && n == 10240) {
+                using S = RfShape<5, 11>;
+                for (int r = 0; r < reps; ++r) switch (std::atoi(dm)) {
+                        case 0: launch_dbg<S, 0>(pl, s.p, int(nrows), size_t(n)); break;
+                        case 1: launch_dbg<S, 1>(pl, s.p, int(nrows), size_t(n)); break;
+                        case 2: launch_dbg<S, 2>(pl, s.p, int(nrows), size_t(n)); break;
+                        default: launch_dbg<S, 3>(pl, s.p, int(nrows), size_t(n)); break;
+                    }
+            } else {
+                for (int r = 0; r < reps; ++r) rowfft_plain(pl, s.p, int(nrows), inverse != 0, nullptr);
+            }
             PFB_HIP(hipEventRecord(b, nullptr));
             PFB_HIP(hipEventSynchronize(b));
             float ms = 0;

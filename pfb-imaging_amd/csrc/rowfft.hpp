@@ -40,6 +40,9 @@ namespace pfbhip {
 #ifndef RF_E32_MINN
 #define RF_E32_MINN 4096
 #endif
+#ifndef RF_TWO_WG_MAXT
+#define RF_TWO_WG_MAXT 1024
+#endif
 constexpr int rf_elems(int N) { return (N >= RF_E32_MINN && N <= RF_E32_MAXN) ? 32 : 16; }
 
 // Doubled shapes N = 2 N1 (N1 = LEAD * 2^K from this list): one workgroup runs the N1-point transforms of the
@@ -314,6 +317,12 @@ __device__ __forceinline__ void dft<16>(double2 (&v)[16])
 // for sub-lengths <= 5, none for the radix-5 exchange) were measured 2 % SLOWER: the transposes are not
 // on the critical path, the extra address arithmetic is.
 __device__ __forceinline__ int rf_swz(int p) { return p ^ ((p >> 4) & 15); }
+// Shapes with an odd leading factor LEAD keep the natural layout instead (SWZ = false): their exchanges scatter with
+// strides LEAD (conflict-free) and 16 LEAD + k (two-way conflicts in ONE exchange of the row), and without the xor every
+// LDS address of an exchange is one per-thread base plus a compile-time offset -- the swizzled form spends 4 integer
+// VALU operations per access, a third of the kernel's VALU time, and these kernels are VALU-bound, not LDS-bound.
+template <bool SWZ>
+__device__ __forceinline__ int rf_pos(int p) { return SWZ ? rf_swz(p) : p; }
 
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the
 // vector-memory counter, which would serialise the prefetched twiddle loads (and the previous row's
@@ -324,17 +333,16 @@ __device__ __forceinline__ void rf_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // j = t + i T, i.e. position expand(j) + dft_index<R>(s) Ns; afterwards slot e holds position t + e T.
 // The row moves one component at a time (N doubles of LDS) or, DUAL, both at once (2 N doubles, half
 // the barriers).
-template <int R, int E, bool DUAL>
-__device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], int t, int T, int N, int Ns, double *lds)
+template <int R, int E, bool DUAL, bool SWZ, int T, int N, int Ns>
+__device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], int t, double *lds)
 {
     constexpr int IT = E / R;
+    static_assert(T % Ns == 0, "the butterfly's offset within its sub-transform must not depend on i");
     // write position of slot i + s IT (recomputed per component: E address registers are worth more
-    // than E integer operations)
-    auto wpos = [&](int i, int s) {
-        const int j = t + i * T;
-        const int k = j % Ns;
-        return rf_swz((j - k) * R + k + dft_index<R>(s) * Ns);
-    };
+    // than E integer operations): one base per thread plus compile-time offsets
+    const int k = t % Ns;
+    const int p0 = (t - k) * R + k;
+    auto wpos = [&](int i, int s) { return rf_pos<SWZ>(p0 + i * T * R + dft_index<R>(s) * Ns); };
     if (DUAL) {
         double *l2 = lds + N;
 #pragma unroll
@@ -348,8 +356,8 @@ __device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], i
         rf_barrier();
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            re[e] = lds[rf_swz(t + e * T)];
-            im[e] = l2[rf_swz(t + e * T)];
+            re[e] = lds[rf_pos<SWZ>(t + e * T)];
+            im[e] = l2[rf_pos<SWZ>(t + e * T)];
         }
         rf_barrier();
     } else {
@@ -359,7 +367,7 @@ __device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], i
             for (int s = 0; s < R; ++s) lds[wpos(i, s)] = re[i + s * IT];
         rf_barrier();
 #pragma unroll
-        for (int e = 0; e < E; ++e) re[e] = lds[rf_swz(t + e * T)];
+        for (int e = 0; e < E; ++e) re[e] = lds[rf_pos<SWZ>(t + e * T)];
         rf_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -368,7 +376,7 @@ __device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], i
             for (int s = 0; s < R; ++s) lds[wpos(i, s)] = im[i + s * IT];
         rf_barrier();
 #pragma unroll
-        for (int e = 0; e < E; ++e) im[e] = lds[rf_swz(t + e * T)];
+        for (int e = 0; e < E; ++e) im[e] = lds[rf_pos<SWZ>(t + e * T)];
         rf_barrier();
     }
 }
@@ -431,9 +439,8 @@ struct rf_load_from_lds<Load, std::void_t<decltype(Load::FROM_LDS)>> : std::bool
 
 // Leading odd pass (radix M = 3 or 5, Ns = 1): N/M butterflies, ceil(E/M) per thread, inputs read
 // straight from the load functor, outputs written straight into the LDS transpose.
-template <int M, int E, bool DUAL, class Load>
-__device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], int t, int T, int N, Load &ld,
-                                             bool inverse, double *lds)
+template <int M, int E, bool DUAL, bool SWZ, int T, int N, class Load>
+__device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], int t, Load &ld, bool inverse, double *lds)
 {
     constexpr int IT = (E + M - 1) / M;
     constexpr bool PRE = rf_load_from_lds<Load>::value;
@@ -465,8 +472,8 @@ __device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], i
             dft<M>(v);
 #pragma unroll
             for (int q = 0; q < M; ++q) {
-                lds[rf_swz(j * M + q)] = v[q].x;
-                if (DUAL) l2[rf_swz(j * M + q)] = v[q].y;
+                lds[rf_pos<SWZ>(j * M + q)] = v[q].x;
+                if (DUAL) l2[rf_pos<SWZ>(j * M + q)] = v[q].y;
             }
         }
         if constexpr (!DUAL) {
@@ -480,8 +487,8 @@ __device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], i
     rf_barrier();
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        re[e] = lds[rf_swz(t + e * T)];
-        if (DUAL) im[e] = l2[rf_swz(t + e * T)];
+        re[e] = lds[rf_pos<SWZ>(t + e * T)];
+        if (DUAL) im[e] = l2[rf_pos<SWZ>(t + e * T)];
     }
     rf_barrier();
     if constexpr (!DUAL) {
@@ -490,34 +497,41 @@ __device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], i
             const int j = t + i * T;
             if (j < nbf) {
 #pragma unroll
-                for (int q = 0; q < M; ++q) lds[rf_swz(j * M + q)] = oim[i * M + q];
+                for (int q = 0; q < M; ++q) lds[rf_pos<SWZ>(j * M + q)] = oim[i * M + q];
             }
         }
         rf_barrier();
 #pragma unroll
-        for (int e = 0; e < E; ++e) im[e] = lds[rf_swz(t + e * T)];
+        for (int e = 0; e < E; ++e) im[e] = lds[rf_pos<SWZ>(t + e * T)];
         rf_barrier();
     }
 }
 
 // Compile-time description of one supported row length.
-template <int LEAD_, int K_, bool ALLOW_DUAL = true, int E_ = 0>
+template <int LEAD_, int K_, bool ALLOW_DUAL = true, int E_ = 0, bool ALLOW_SPLIT = true>
 struct RfShape {
     static constexpr int LEAD = LEAD_, K = K_;
     static constexpr int N = LEAD_ << K_, E = E_ > 0 ? E_ : rf_elems(N), T = N / E;
     static constexpr bool DOUBLED = false;
     static constexpr int NSLOT = LEAD_ > 1 ? ((E + LEAD_ - 1) / LEAD_) * LEAD_ : E;  // load-functor slots per row
     static constexpr int NP = rf_npass(K_);
+    static constexpr bool SWZ = LEAD_ == 1;  // LDS layout of the exchanges (see rf_pos)
     static constexpr int RLAST = rf_radix(K_, NP - 1);
-    // E = 32 shapes run two workgroups per CU and therefore transpose one component at a time
+    // Two workgroups per CU wherever they fit (LDS: 2 x N doubles when the row moves one component at a time; waves: 2 T / 64
+    // <= 20, i.e. 5 per SIMD and 96 VGPRs, which the straight-line passes meet since their LDS addresses are base + constant):
+    // the exchanges are barrier-separated phases in which the whole workgroup either writes LDS, reads LDS or computes, so ONE
+    // workgroup leaves the VALU idle during its exchanges and the LDS idle during its butterflies (measured at N = 10240:
+    // passes alone 11.4 us per row, of which ~5 us VALU and ~4.5 us LDS); a second one fills those gaps and overlaps the
+    // global loads / stores of one row with the passes of the other.
+    static constexpr bool TWO_WG_SPLIT = ALLOW_DUAL && ALLOW_SPLIT && E == 16 && 2 * N * int(sizeof(double)) <= 160 * 1024 && 2 * T <= RF_TWO_WG_MAXT;
 #ifdef RF_NO_DUAL
     static constexpr bool DUAL = false;
 #else
-    static constexpr bool DUAL = ALLOW_DUAL && E == 16 && N * 16 <= 160 * 1024;
+    static constexpr bool DUAL = ALLOW_DUAL && E == 16 && N * 16 <= 160 * 1024 && !(TWO_WG_SPLIT && 2 * N * 16 > 160 * 1024);
 #endif
     static constexpr int LDS_BYTES = (DUAL ? 2 : 1) * N * int(sizeof(double));
     // (the fused kernels, ALLOW_DUAL = false, add their image row to the LDS: one workgroup per CU)
-    static constexpr int WG_PER_CU = (ALLOW_DUAL && 2 * LDS_BYTES <= 160 * 1024 && 2 * T <= 1024) ? 2 : 1;
+    static constexpr int WG_PER_CU = (ALLOW_DUAL && 2 * LDS_BYTES <= 160 * 1024 && 2 * T <= RF_TWO_WG_MAXT) ? 2 : 1;
     static constexpr int WAVES_PER_SIMD = (WG_PER_CU * ((T + 63) / 64) + 3) / 4;  // register budget = 512 / this
     // position of the value left in slot e after the last pass
     static __device__ __forceinline__ int out_pos(int t, int e) { return t + rf_last_slot(RLAST, E, e) * T; }
@@ -532,6 +546,7 @@ struct RfShape2 {
     static constexpr int N = 2 * S1::N, E = 2 * S1::E, T = S1::T;
     static constexpr int NSLOT = 2 * S1::NSLOT;
     static constexpr bool DUAL = S1::DUAL;
+    static constexpr bool SWZ = S1::SWZ;
     static constexpr int LDS_BYTES = S1::LDS_BYTES;
     static constexpr int WG_PER_CU = 1;
     static constexpr int WAVES_PER_SIMD = ((T + 63) / 64 + 3) / 4;
@@ -555,7 +570,7 @@ __device__ __forceinline__ void rf_passes(double (&re)[S::E], double (&im)[S::E]
         constexpr int R2 = rf_radix(S::K, P + 1);
         double2 w2[S::E / R2];
         rf_load_twiddles<R2, S::E>(w2, t, S::T, S::N, NS * R, tw);
-        rf_transpose<R, S::E, S::DUAL>(re, im, t, S::T, S::N, NS, lds);
+        rf_transpose<R, S::E, S::DUAL, S::SWZ, S::T, S::N, NS>(re, im, t, lds);
         rf_passes<S, P + 1, NS * R>(re, im, t, tw, lds, w2);
     }
 }
@@ -604,7 +619,7 @@ __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, L
     double2 w0[S::E / R0] = {};
     if constexpr (S::LEAD > 1) {
         rf_load_twiddles<R0, S::E>(w0, t, S::T, S::N, S::LEAD, tw);
-        rf_first_odd<S::LEAD, S::E, S::DUAL>(re, im, t, S::T, S::N, ld, inverse, lds);
+        rf_first_odd<S::LEAD, S::E, S::DUAL, S::SWZ, S::T, S::N>(re, im, t, ld, inverse, lds);
     } else {
 #pragma unroll
         for (int e = 0; e < S::E; ++e) {

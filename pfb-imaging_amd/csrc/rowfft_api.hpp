@@ -25,14 +25,16 @@ void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inver
 //   a2b: B[y][u] = IFFT_v(A[u][:])[wrap(y - ny/2)]   b2a: A[u][:] = FFT_v(v -> B[y(v)][u], 0 outside the image)
 void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, const int *rowmap_dev, int nrows, int nu, int ny,
                 size_t apitch, hipStream_t stream);
+// tpitch > 0: B_dev is Bt[u][y] (tpitch elements per row u, FusedGeom::tpitch): contiguous loads, no transpose here
 void rowfft_b2a(const RowFFTPlan &pl, const double2 *B_dev, double2 *A_dev, const int *rowmap_dev, int nrows, int nu, int ny,
-                size_t apitch, hipStream_t stream);
+                size_t apitch, int tpitch, hipStream_t stream);
 
 // Geometry of the second-axis (u) pass of the gridder's plane transform.
 constexpr int FUSED_MAXPOLY = 20;
 struct FusedGeom {
     int nx, ny, nu;
     int bpitch;  // complex elements between consecutive rows of B (>= nu; padded off the power-of-two pitch, see gridder.hip)
+    int tpitch;  // > 0: the fused pad kernel stores TRANSPOSED, Bt[u][y] with this many elements per row u (0: B[y][u])
     double px, py, lshift, mshift, nshift;
     // n - 1 = sqrt(1 - r2) - 1 as a polynomial in s = r2 * za + zb in [-1, 1] (npoly coefficients, highest
     // first); npoly = 0: evaluate the square root (wide fields).  Filled by fused_geom_fit().
