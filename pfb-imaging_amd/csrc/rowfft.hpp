@@ -517,12 +517,13 @@ struct RfShape {
     static constexpr int NP = rf_npass(K_);
     static constexpr bool SWZ = LEAD_ == 1;  // LDS layout of the exchanges (see rf_pos)
     static constexpr int RLAST = rf_radix(K_, NP - 1);
-    // Two workgroups per CU wherever they fit (LDS: 2 x N doubles when the row moves one component at a time; waves: 2 T / 64
-    // <= 20, i.e. 5 per SIMD and 96 VGPRs, which the straight-line passes meet since their LDS addresses are base + constant):
-    // the exchanges are barrier-separated phases in which the whole workgroup either writes LDS, reads LDS or computes, so ONE
-    // workgroup leaves the VALU idle during its exchanges and the LDS idle during its butterflies (measured at N = 10240:
-    // passes alone 11.4 us per row, of which ~5 us VALU and ~4.5 us LDS); a second one fills those gaps and overlaps the
-    // global loads / stores of one row with the passes of the other.
+    // Two workgroups per CU where they fit (LDS: 2 x N doubles when the row moves one component at a time; threads: 2 T <=
+    // RF_TWO_WG_MAXT = 1024, i.e. 4 waves per SIMD and 128 VGPRs): the exchanges are barrier-separated phases in which the whole
+    // workgroup writes LDS, reads LDS or computes, so one workgroup leaves the VALU idle during its exchanges and the LDS idle
+    // during its butterflies.  Measured (tools/rowfft_probe.py, 4096 rows): N = 8192 0.222 -> 0.201 ms.  With T = 640 (N = 10240)
+    // the second workgroup means 5 waves per SIMD and 96 VGPRs: the plain transform fits without spills but gains nothing
+    // (0.343 -> 0.350 ms, it is HBM-bound at 4.7 TB/s), the transposing store spills (0.43 -> 0.65 ms) and the fused pad kernel
+    // loses its LDS image row (1.90 -> 2.34 ms) -- RF_TWO_WG_MAXT stays at 1024.
     static constexpr bool TWO_WG_SPLIT = ALLOW_DUAL && ALLOW_SPLIT && E == 16 && 2 * N * int(sizeof(double)) <= 160 * 1024 && 2 * T <= RF_TWO_WG_MAXT;
 #ifdef RF_NO_DUAL
     static constexpr bool DUAL = false;
