@@ -40,6 +40,9 @@ namespace pfbhip {
 #ifndef RF_E32_MINN
 #define RF_E32_MINN 4096
 #endif
+#ifndef RF_XPAD
+#define RF_XPAD 2
+#endif
 #ifndef RF_TWO_WG_MAXT
 #define RF_TWO_WG_MAXT 1024
 #endif
@@ -333,16 +336,23 @@ __device__ __forceinline__ void rf_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // j = t + i T, i.e. position expand(j) + dft_index<R>(s) Ns; afterwards slot e holds position t + e T.
 // The row moves one component at a time (N doubles of LDS) or, DUAL, both at once (2 N doubles, half
 // the barriers).
-template <int R, int E, bool DUAL, bool SWZ, int T, int N, int Ns>
+template <int R, int E, bool DUAL, bool SWZ, int T, int N, int Ns, int PAD>
 __device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], int t, double *lds)
 {
     constexpr int IT = E / R;
     static_assert(T % Ns == 0, "the butterfly's offset within its sub-transform must not depend on i");
+    static_assert(PAD == 0 || (!SWZ && !DUAL && T % (R * Ns) == 0), "padded exchange: natural layout, one component, whole blocks per e");
     // write position of slot i + s IT (recomputed per component: E address registers are worth more
-    // than E integer operations): one base per thread plus compile-time offsets
+    // than E integer operations): one base per thread plus compile-time offsets.
+    // PAD > 0: every block of R Ns positions (one butterfly group a = t / Ns) is followed by PAD unused doubles.  In the
+    // natural layout the lanes of a write instruction sit at R Ns a + k (k < Ns), i.e. on (R Ns mod 32) a + k double-banks:
+    // with R Ns = 16 LEAD that is 16 a + k, LEAD + LEAD of 32 bank pairs, a 3- to 4-way conflict; two more doubles per
+    // block walk the groups over the banks (18 a + k).
     const int k = t % Ns;
-    const int p0 = (t - k) * R + k;
-    auto wpos = [&](int i, int s) { return rf_pos<SWZ>(p0 + i * T * R + dft_index<R>(s) * Ns); };
+    const int p0 = (t - k) * R + k + PAD * ((t - k) / Ns);
+    auto wpos = [&](int i, int s) { return rf_pos<SWZ>(p0 + i * (T * R + PAD * (T / Ns)) + dft_index<R>(s) * Ns); };
+    const int r0 = PAD > 0 ? t + PAD * (t / (R * Ns)) : t;
+    constexpr int RS = PAD > 0 ? T + PAD * (T / (R * Ns)) : T;  // reader's step per slot
     if (DUAL) {
         double *l2 = lds + N;
 #pragma unroll
@@ -356,8 +366,8 @@ __device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], i
         rf_barrier();
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            re[e] = lds[rf_pos<SWZ>(t + e * T)];
-            im[e] = l2[rf_pos<SWZ>(t + e * T)];
+            re[e] = lds[rf_pos<SWZ>(r0 + e * RS)];
+            im[e] = l2[rf_pos<SWZ>(r0 + e * RS)];
         }
         rf_barrier();
     } else {
@@ -367,7 +377,7 @@ __device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], i
             for (int s = 0; s < R; ++s) lds[wpos(i, s)] = re[i + s * IT];
         rf_barrier();
 #pragma unroll
-        for (int e = 0; e < E; ++e) re[e] = lds[rf_pos<SWZ>(t + e * T)];
+        for (int e = 0; e < E; ++e) re[e] = lds[rf_pos<SWZ>(r0 + e * RS)];
         rf_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -376,7 +386,7 @@ __device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], i
             for (int s = 0; s < R; ++s) lds[wpos(i, s)] = im[i + s * IT];
         rf_barrier();
 #pragma unroll
-        for (int e = 0; e < E; ++e) im[e] = lds[rf_pos<SWZ>(t + e * T)];
+        for (int e = 0; e < E; ++e) im[e] = lds[rf_pos<SWZ>(r0 + e * RS)];
         rf_barrier();
     }
 }
@@ -530,7 +540,9 @@ struct RfShape {
 #else
     static constexpr bool DUAL = ALLOW_DUAL && E == 16 && N * 16 <= 160 * 1024 && !(TWO_WG_SPLIT && 2 * N * 16 > 160 * 1024);
 #endif
-    static constexpr int LDS_BYTES = (DUAL ? 2 : 1) * N * int(sizeof(double));
+    // unused doubles behind every 16 LEAD positions of the exchange after the first radix-16 pass (see rf_transpose)
+    static constexpr int XPAD = (!DUAL && LEAD_ > 1 && K_ >= 8 && E == 16) ? RF_XPAD : 0;
+    static constexpr int LDS_BYTES = ((DUAL ? 2 : 1) * N + XPAD * (N / (16 * LEAD_))) * int(sizeof(double));
     // (the fused kernels, ALLOW_DUAL = false, add their image row to the LDS: one workgroup per CU)
     static constexpr int WG_PER_CU = (ALLOW_DUAL && 2 * LDS_BYTES <= 160 * 1024 && 2 * T <= RF_TWO_WG_MAXT) ? 2 : 1;
     static constexpr int WAVES_PER_SIMD = (WG_PER_CU * ((T + 63) / 64) + 3) / 4;  // register budget = 512 / this
@@ -548,6 +560,7 @@ struct RfShape2 {
     static constexpr int NSLOT = 2 * S1::NSLOT;
     static constexpr bool DUAL = S1::DUAL;
     static constexpr bool SWZ = S1::SWZ;
+    static constexpr int XPAD = S1::XPAD;
     static constexpr int LDS_BYTES = S1::LDS_BYTES;
     static constexpr int WG_PER_CU = 1;
     static constexpr int WAVES_PER_SIMD = ((T + 63) / 64 + 3) / 4;
@@ -571,7 +584,7 @@ __device__ __forceinline__ void rf_passes(double (&re)[S::E], double (&im)[S::E]
         constexpr int R2 = rf_radix(S::K, P + 1);
         double2 w2[S::E / R2];
         rf_load_twiddles<R2, S::E>(w2, t, S::T, S::N, NS * R, tw);
-        rf_transpose<R, S::E, S::DUAL, S::SWZ, S::T, S::N, NS>(re, im, t, lds);
+        rf_transpose<R, S::E, S::DUAL, S::SWZ, S::T, S::N, NS, (R == 16 && NS == S::LEAD) ? S::XPAD : 0>(re, im, t, lds);
         rf_passes<S, P + 1, NS * R>(re, im, t, tw, lds, w2);
     }
 }
