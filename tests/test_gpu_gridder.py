@@ -428,6 +428,33 @@ def test_fused_row_fft_path(monkeypatch):
         assert rel(d2, d0) < tol
 
 
+def test_first_axis_variants_agree(monkeypatch):
+    """The first axis of the plane transform in its four forms -- transposing row FFT with the degridding side stored
+    transposed by the fused pad kernel (default), the same with gathered loads (PFBHIP_TPAD=0), without the XCD-aware
+    row order (PFBHIP_TFFT=2), and the plain row FFT with separate transpose kernels (PFBHIP_TFFT=0) -- is the same
+    arithmetic on the same numbers: results agree to rounding.  1100 x 1000 pixels: neither image axis is a multiple of
+    the 64-row groups of the transposed stores."""
+    c = make(nrow=2000, npix=64, widen=8.0, zscale=0.05)
+    rng = np.random.default_rng(11)
+    c["nx"], c["ny"] = 1100, 1000
+    c["cell"] = c["cell"] * 64.0 / 1100
+    c["x"] = rng.standard_normal((1100, 1000))
+    outs = []
+    for env in ({}, {"PFBHIP_TPAD": "0"}, {"PFBHIP_TFFT": "2"}, {"PFBHIP_TFFT": "0"}):
+        for k in ("PFBHIP_TPAD", "PFBHIP_TFFT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g, kw, mask = gpu_plan(c)
+        assert g.info["fft_mode"] & 3 == 3
+        assert bool(g.info["fft_mode"] & 8) == (env.get("PFBHIP_TFFT") != "0")
+        g.set_weights(c["wgt"])
+        outs.append((g.vis2dirty(c["vis"], c["wgt"]), g.dirty2vis(c["x"]), g.hessian(c["x"])))
+        g.close()
+    for d, v, h in outs[1:]:
+        assert rel(d, outs[0][0]) < 1e-11 and rel(v, outs[0][1]) < 1e-11 and rel(h, outs[0][2]) < 1e-11  # (LDS atomics: run-to-run 1e-13)
+
+
 @pytest.mark.parametrize("nx,ny,center,widen,zscale", [
     (1200, 1000, (0.0, 0.0), 8.0, 0.02),        # grid 1536 x 1280 (3 * 2^9, 5 * 2^8): leading radix-3 and -5 passes
     (1600, 840, (0.003, -0.002), 8.0, 0.05),     # grid 2048 x 1280 / 1024: rectangular, shifted phase centre
