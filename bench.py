@@ -83,9 +83,10 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
             "pad_fft": 2 * I + ppl * occ * B,
         })
         launches.update({"fft_crop": ngroups, "pad_fft": ngroups})
-        if tfft:  # first axis with the crop / pad + transpose folded in: occupied rows of A on one side, occupied columns of B on the other
-            per_launch["fft_rows"] = occ * G + occ * B
-            launches["fft_rows"] = 2 * P
+        if tfft:  # first axis with the crop / pad + transpose folded in: occupied rows of A on one side, occupied columns of B
+            # on the other; one launch per direction takes every plane of the pass
+            per_launch["fft_rows"] = ppl * (occ * G + occ * B)
+            launches["fft_rows"] = 2 * ngroups
         else:
             per_launch.update({"fft_rows": 2 * occ * G, "pad": occ * B + occ * G, "crop": occ * (ny / info["nv"]) * G + occ * B})
             launches.update({"fft_rows": 2 * P * 2, "pad": P, "crop": P})  # (two row spans per plane and direction)

@@ -838,15 +838,14 @@ struct pfbhip_gridder {
             }
             PFB_W_DISPATCH(launch_grid_mp_w, p0, kp, sval);  // stage 0, timed per kernel launch inside
             PFB_HIP(hipGetLastError());
-            for (int k = 0; k < kp; ++k) {
+            if (tfft) {  // every plane of the pass in one launch
+                timer.begin(2);
+                rowfft_a2b(rowfft_v.pl, grid_cur, d_gridB.p, d_rowmap.p, int(occ_rows), geom.bpitch, int(prm.ny), size_t(geom.apitch),
+                           kp, plane_stride, bstride, stream);
+                timer.end();
+            }
+            for (int k = 0; k < kp && !tfft; ++k) {
                 const int p = p0 + k;
-                if (tfft) {
-                    timer.begin(2);
-                    rowfft_a2b(rowfft_v.pl, grid_cur + size_t(k) * plane_stride, d_gridB.p + size_t(k) * bstride, d_rowmap.p,
-                               int(occ_rows), geom.bpitch, int(prm.ny), size_t(geom.apitch), stream);
-                    timer.end();
-                    continue;
-                }
                 fft_rows_A(false, k);
                 timer.begin(4);
                 hipLaunchKernelGGL(k_a2b, tgrid(info.nu, prm.ny), dim3(TP, TRANSPOSE_ROWS), 0, stream, geom, d_occ.p,
@@ -953,7 +952,13 @@ struct pfbhip_gridder {
                               fused_planes(p0, kp), prm.do_wgridding, d_gridB.p, bstride, stream);
                 timer.end();
             }
-            for (int k = 0; k < kp; ++k) {
+            if (tfft) {
+                timer.begin(2);
+                rowfft_b2a(rowfft_v.pl, d_gridB.p, grid_cur, d_rowmap.p, int(occ_rows), geom.bpitch, int(prm.ny), size_t(geom.apitch),
+                           fgeom.tpitch, kp, plane_stride, bstride, stream);
+                timer.end();
+            }
+            for (int k = 0; k < kp && !tfft; ++k) {
                 const int p = p0 + k;
                 if (!fused) {
                     timer.begin(3);
@@ -963,13 +968,6 @@ struct pfbhip_gridder {
                     PFB_HIP(hipGetLastError());
                     timer.end();
                     fft_rows_B(true);
-                }
-                if (tfft) {
-                    timer.begin(2);
-                    rowfft_b2a(rowfft_v.pl, d_gridB.p + size_t(k) * bstride, grid_cur + size_t(k) * plane_stride, d_rowmap.p,
-                               int(occ_rows), geom.bpitch, int(prm.ny), size_t(geom.apitch), fgeom.tpitch, stream);
-                    timer.end();
-                    continue;
                 }
                 timer.begin(3);
                 hipLaunchKernelGGL(k_b2a, tgrid(info.nu, info.nv), dim3(TP, TRANSPOSE_ROWS), 0, stream, geom, d_occ.p,
