@@ -529,6 +529,7 @@ struct pfbhip_gridder {
     // work.  Clearing those -- per tile row the runs of touched tile columns, 8-row slices -- instead of every occupied row
     // moves a third of the bytes when the uv coverage is a disc (C2: 0.9 of 2.4 GB).
     DevBuf<int4> d_clear_rects;
+    DevBuf<int4> d_colruns;  // per tile row: the column runs in use (transposing first-axis FFT: RunLoad / RunStore)
     int n_clear_rects = 0;
     double2 *grid_cur = nullptr;  // the plane buffer the pipeline stages work on (d_grid unless a Hessian switched it)
     hipStream_t clear_stream = nullptr;
@@ -866,7 +867,7 @@ struct pfbhip_gridder {
             if (tfft) {  // every plane of the pass in one launch
                 timer.begin(2);
                 rowfft_a2b(rowfft_v.pl, grid_cur, d_gridB.p, d_rowmap.p, int(occ_rows), geom.bpitch, int(prm.ny), size_t(geom.apitch),
-                           kp, plane_stride, bstride, stream);
+                           kp, plane_stride, bstride, d_colruns.p, stream);
                 timer.end();
             }
             for (int k = 0; k < kp && !tfft; ++k) {
@@ -980,7 +981,7 @@ struct pfbhip_gridder {
             if (tfft) {
                 timer.begin(2);
                 rowfft_b2a(rowfft_v.pl, d_gridB.p, grid_cur, d_rowmap.p, int(occ_rows), geom.bpitch, int(prm.ny), size_t(geom.apitch),
-                           fgeom.tpitch, kp, plane_stride, bstride, stream);
+                           fgeom.tpitch, kp, plane_stride, bstride, d_colruns.p, stream);
                 timer.end();
             }
             for (int k = 0; k < kp && !tfft; ++k) {
@@ -1638,6 +1639,38 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         int64_t last_row = (tu * TILE + TILE + info.W - 2) % info.nu;  // last cell row the tile's footprint can touch
         occ[size_t(last_row / TP)] = 1;
         if (tu * TILE + TILE + info.W - 2 >= info.nu) occ[0] = 1;
+    }
+    {   // column runs per tile row (default: the whole row)
+        const int64_t ntu_t = ceil_div(info.nu, TILE), ntv_t = m.ntv;
+        std::vector<int4> runs_t(size_t(ntu_t), make_int4(0, int(info.nv), 0, 0));
+        if (!work.empty()) {
+            std::vector<uint8_t> touched(size_t(ntu_t * ntv_t), 0);
+            for (const WorkItem &wi : work) {
+                const int64_t tu = wi.tile / uint32_t(m.ntv), tv = wi.tile % uint32_t(m.ntv);
+                for (int du = 0; du < 2; ++du)
+                    for (int dv = 0; dv < 2; ++dv)
+                        touched[size_t(((tu + du) % ntu_t) * ntv_t + (tv + dv) % ntv_t)] = 1;
+            }
+            for (int64_t tu = 0; tu < ntu_t; ++tu) {
+                std::vector<std::pair<int, int>> rr;
+                for (int64_t tv = 0; tv < ntv_t;) {
+                    if (!touched[size_t(tu * ntv_t + tv)]) { ++tv; continue; }
+                    int64_t e = tv;
+                    while (e < ntv_t && touched[size_t(tu * ntv_t + e)]) ++e;
+                    rr.emplace_back(int(tv * TILE), int(std::min<int64_t>(e * TILE, info.nv)));
+                    tv = e;
+                }
+                if (rr.size() == 1) runs_t[size_t(tu)] = make_int4(rr[0].first, rr[0].second, 0, 0);
+                else if (rr.size() == 2) runs_t[size_t(tu)] = make_int4(rr[0].first, rr[0].second, rr[1].first, rr[1].second);
+                else if (rr.empty()) runs_t[size_t(tu)] = make_int4(0, 0, 0, 0);
+                // (three or more runs: the whole row)
+            }
+        }
+        if (std::getenv("PFBHIP_COLRUNS") != nullptr && std::getenv("PFBHIP_COLRUNS")[0] == '0')
+            std::fill(runs_t.begin(), runs_t.end(), make_int4(0, int(info.nv), 0, 0));
+        g->d_colruns.alloc(runs_t.size());
+        PFB_HIP(hipMemcpyAsync(g->d_colruns.p, runs_t.data(), runs_t.size() * sizeof(int4), hipMemcpyHostToDevice, st));
+        PFB_HIP(hipStreamSynchronize(st));
     }
     if (g->async_clear && !work.empty()) {
         const int64_t ntu_t = ceil_div(info.nu, TILE), ntv_t = m.ntv;

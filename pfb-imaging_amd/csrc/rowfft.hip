@@ -22,6 +22,25 @@ struct PlainStore {
     double2 *row;
     __device__ __forceinline__ void operator()(int i, double2 v) const { row[i] = v; }
 };
+// Row of a uv-plane of which only the columns [r.x, r.y) and [r.z, r.w) are in use (the tile columns the row's tile row has
+// visibilities in, plus their halo): the rest is zero by construction on the gridding side and never read on the degridding
+// side -- with a disc-shaped uv coverage two thirds of an occupied row.
+struct RunLoad {
+    const double2 *row;
+    int4 r;
+    __device__ __forceinline__ double2 operator()(int i, int) const
+    {
+        return ((i >= r.x && i < r.y) || (i >= r.z && i < r.w)) ? row[i] : make_double2(0.0, 0.0);
+    }
+};
+struct RunStore {
+    double2 *row;
+    int4 r;
+    __device__ __forceinline__ void operator()(int i, double2 v) const
+    {
+        if ((i >= r.x && i < r.y) || (i >= r.z && i < r.w)) row[i] = v;
+    }
+};
 
 // One row per workgroup, S::T threads; the register budget follows from the workgroup size
 // (512 threads -> 256 VGPRs, 640/768 -> 168, 1024 -> 128); the straight-line passes need ~165.
@@ -144,14 +163,14 @@ struct PadTLoad {
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_a2b(const double2 *tw, const double2 *A, double2 *B,
                                                                           const int *rowmap, int nrows, int nu, int ny, size_t apitch,
-                                                                          size_t astride, size_t bstride)
+                                                                          size_t astride, size_t bstride, const int4 *colruns)
 {
     extern __shared__ double rf_lds[];
     if (int(blockIdx.x) >= nrows) return;
     const int u = rowmap[blockIdx.x];
     A += size_t(blockIdx.y) * astride;
     B += size_t(blockIdx.y) * bstride;
-    PlainLoad ld{A + size_t(u) * apitch};
+    RunLoad ld{A + size_t(u) * apitch, colruns[u >> 5]};
     CropTStore st{B, u, nu, ny, S::N, ny / 2};
     rf_row<S>(tw, ld, st, true, rf_lds);
 }
@@ -172,14 +191,14 @@ struct PadRowLoad {
 template <class S, bool TR>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_b2a(const double2 *tw, const double2 *B, double2 *A,
                                                                           const int *rowmap, int nrows, int nu, int ny, size_t apitch,
-                                                                          int tpitch, size_t astride, size_t bstride)
+                                                                          int tpitch, size_t astride, size_t bstride, const int4 *colruns)
 {
     extern __shared__ double rf_lds[];
     if (int(blockIdx.x) >= nrows) return;
     const int u = rowmap[blockIdx.x];
     A += size_t(blockIdx.y) * astride;
     B += size_t(blockIdx.y) * bstride;
-    PlainStore st{A + size_t(u) * apitch};
+    RunStore st{A + size_t(u) * apitch, colruns[u >> 5]};
     if constexpr (TR) {
         PadRowLoad ld{B + size_t(u) * size_t(tpitch), ny, S::N, ny / 2};
         rf_row<S>(tw, ld, st, false, rf_lds);
@@ -191,38 +210,38 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_b2a(const do
 
 template <class S>
 static void launch_a2b(const RowFFTPlan &pl, const double2 *A, double2 *B, const int *rowmap, int nrows, int nu, int ny,
-                       size_t apitch, int nplanes, size_t astride, size_t bstride, hipStream_t stream)
+                       size_t apitch, int nplanes, size_t astride, size_t bstride, const int4 *colruns, hipStream_t stream)
 {
     static bool attr = false;
     rf_allow_lds(&k_rowfft_a2b<S>, &attr);
     // (grid.x a multiple of 8: a plane's workgroups then start on XCD 0 like the first plane's -- rowmap relies on it)
     hipLaunchKernelGGL((k_rowfft_a2b<S>), dim3(uint32_t((nrows + 7) / 8 * 8), uint32_t(nplanes)), dim3(S::T), size_t(S::LDS_BYTES),
-                       stream, pl.twiddle, A, B, rowmap, nrows, nu, ny, apitch, astride, bstride);
+                       stream, pl.twiddle, A, B, rowmap, nrows, nu, ny, apitch, astride, bstride, colruns);
 }
 template <class S>
 static void launch_b2a(const RowFFTPlan &pl, const double2 *B, double2 *A, const int *rowmap, int nrows, int nu, int ny,
-                       size_t apitch, int tpitch, int nplanes, size_t astride, size_t bstride, hipStream_t stream)
+                       size_t apitch, int tpitch, int nplanes, size_t astride, size_t bstride, const int4 *colruns, hipStream_t stream)
 {
     static bool attr = false, attr_t = false;
     const dim3 grid(uint32_t((nrows + 7) / 8 * 8), uint32_t(nplanes));
     if (tpitch > 0) {
         rf_allow_lds(&k_rowfft_b2a<S, true>, &attr_t);
         hipLaunchKernelGGL((k_rowfft_b2a<S, true>), grid, dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A, rowmap, nrows,
-                           nu, ny, apitch, tpitch, astride, bstride);
+                           nu, ny, apitch, tpitch, astride, bstride, colruns);
         return;
     }
     rf_allow_lds(&k_rowfft_b2a<S, false>, &attr);
     hipLaunchKernelGGL((k_rowfft_b2a<S, false>), grid, dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A, rowmap, nrows, nu,
-                       ny, apitch, 0, astride, bstride);
+                       ny, apitch, 0, astride, bstride, colruns);
 }
 
 void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, const int *rowmap_dev, int nrows, int nu, int ny,
-                size_t apitch, int nplanes, size_t astride, size_t bstride, hipStream_t stream)
+                size_t apitch, int nplanes, size_t astride, size_t bstride, const int4 *colruns, hipStream_t stream)
 {
     PFB_REQUIRE(!pl.doubled, "transposing row FFT: doubled shapes are not supported");
     switch (pl.N) {
 #define RF_X(L, K)                                                                       \
-    case (L << K): launch_a2b<RfShape<L, K>>(pl, A_dev, B_dev, rowmap_dev, nrows, nu, ny, apitch, nplanes, astride, bstride, stream); break;
+    case (L << K): launch_a2b<RfShape<L, K>>(pl, A_dev, B_dev, rowmap_dev, nrows, nu, ny, apitch, nplanes, astride, bstride, colruns, stream); break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);
@@ -231,12 +250,12 @@ void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, cons
 }
 
 void rowfft_b2a(const RowFFTPlan &pl, const double2 *B_dev, double2 *A_dev, const int *rowmap_dev, int nrows, int nu, int ny,
-                size_t apitch, int tpitch, int nplanes, size_t astride, size_t bstride, hipStream_t stream)
+                size_t apitch, int tpitch, int nplanes, size_t astride, size_t bstride, const int4 *colruns, hipStream_t stream)
 {
     PFB_REQUIRE(!pl.doubled, "transposing row FFT: doubled shapes are not supported");
     switch (pl.N) {
 #define RF_X(L, K)                                                                       \
-    case (L << K): launch_b2a<RfShape<L, K>>(pl, B_dev, A_dev, rowmap_dev, nrows, nu, ny, apitch, tpitch, nplanes, astride, bstride, stream); break;
+    case (L << K): launch_b2a<RfShape<L, K>>(pl, B_dev, A_dev, rowmap_dev, nrows, nu, ny, apitch, tpitch, nplanes, astride, bstride, colruns, stream); break;
         RF_FOR_SHAPES(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);

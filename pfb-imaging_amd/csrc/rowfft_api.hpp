@@ -23,12 +23,13 @@ void rowfft_plain(const RowFFTPlan &pl, double2 *data_dev, int nrows, bool inver
 // load: rowmap_dev[b] is the row of workgroup b (see rowfft.hip: the 8 rows of a 128-byte line of B share an XCD); nu here is the
 // row pitch of B, apitch that of A (complex elements).
 //   a2b: B[y][u] = IFFT_v(A[u][:])[wrap(y - ny/2)]   b2a: A[u][:] = FFT_v(v -> B[y(v)][u], 0 outside the image)
-// nplanes planes per launch, astride / bstride elements apart in A / B
+// nplanes planes per launch, astride / bstride elements apart in A / B; colruns_dev[u >> 5] = the (at most two) column runs
+// [x, y) and [z, w) of A that rows of tile row u >> 5 use (loads outside them read as zero, stores outside them are dropped)
 void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, const int *rowmap_dev, int nrows, int nu, int ny,
-                size_t apitch, int nplanes, size_t astride, size_t bstride, hipStream_t stream);
+                size_t apitch, int nplanes, size_t astride, size_t bstride, const int4 *colruns_dev, hipStream_t stream);
 // tpitch > 0: B_dev is Bt[u][y] (tpitch elements per row u, FusedGeom::tpitch): contiguous loads, no transpose here
 void rowfft_b2a(const RowFFTPlan &pl, const double2 *B_dev, double2 *A_dev, const int *rowmap_dev, int nrows, int nu, int ny,
-                size_t apitch, int tpitch, int nplanes, size_t astride, size_t bstride, hipStream_t stream);
+                size_t apitch, int tpitch, int nplanes, size_t astride, size_t bstride, const int4 *colruns_dev, hipStream_t stream);
 
 // Geometry of the second-axis (u) pass of the gridder's plane transform.
 constexpr int FUSED_MAXPOLY = 20;
