@@ -68,11 +68,14 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
     rec = info.get("scatter_mode", 0) == 2
     nsl = max(int(info.get("scatter_launches", 1)), 1)
     vis_rec = 32 + (16 * ppl if rec else 40)  # per visibility and pass: record + values (k_grid_rec) / coordinates + value
+    # cells of a plane the scatter / gather can touch (tiles with visibilities + halo): what the first-axis transforms and the
+    # plane clear move of the occupied rows
+    Au = info.get("used_cells", 0) * Sc or occ * G
     per_launch = {
-        # occupied plane rows written (read-add-written by tile) once + the visibility records; one launch per tile colour
-        "grid": (ppl * occ * G + nactive * vis_rec) / nsl,
-        # occupied plane rows read once + records (+ the plane-weighted values it writes inside a Hessian apply)
-        "degrid": ppl * occ * G + nactive * (32 + 8 * ppl + (16 * ppl if rec else 16)),
+        # used plane cells written (read-add-written by tile) once + the visibility records; one launch per tile colour
+        "grid": (ppl * Au + nactive * vis_rec) / nsl,
+        # used plane cells read once + records (+ the plane-weighted values it writes inside a Hessian apply)
+        "degrid": ppl * Au + nactive * (32 + 8 * ppl + (16 * ppl if rec else 16)),
     }
     launches = {"grid": ngroups * nsl, "degrid": ngroups}
     if fused:
@@ -85,7 +88,7 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
         launches.update({"fft_crop": ngroups, "pad_fft": ngroups})
         if tfft:  # first axis with the crop / pad + transpose folded in: occupied rows of A on one side, occupied columns of B
             # on the other; one launch per direction takes every plane of the pass
-            per_launch["fft_rows"] = ppl * (occ * G + occ * B)
+            per_launch["fft_rows"] = ppl * (Au + occ * B)
             launches["fft_rows"] = 2 * ngroups
         else:
             per_launch.update({"fft_rows": 2 * occ * G, "pad": occ * B + occ * G, "crop": occ * (ny / info["nv"]) * G + occ * B})
@@ -95,7 +98,7 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
         per_launch.update({"fft_rows": occ * G + B, "pad": (I + B + occ * B + occ * G) / 2,
                            "crop": (occ * (ny / info["nv"]) * G + B + (nx / info["nu"]) * B + 2 * I) / 2})
         launches.update({"fft_rows": 4 * P, "pad": 2 * P, "crop": 2 * P})
-    other = P * occ * G  # clearing the occupied rows of the scatter's planes (memset; on a side stream in single-pass plans)
+    other = P * Au  # clearing the used cells of the scatter's planes (on a side stream in single-pass plans)
     return b_vis + b_grid, per_launch, launches, other
 
 
@@ -426,7 +429,7 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
                 "bound": "hbm", "kernel": names.get(dom, dom), "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 # not measured in this run: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) are separate runs, see profiles/
-                "traffic": None, "traffic_profile": "profiles/r02d_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
+                "traffic": None, "traffic_profile": "profiles/r02e_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
                 "alg_bytes_per_launch": per_launch[dom], "avg_launch_ms": avg_ms, "launches": dom_calls,
                 "actual_bytes_per_apply": actual,
                 "actual_frac": actual / apply_s / 1e9 / HBM_PEAK_GBS,

@@ -113,15 +113,20 @@ typedef struct pfbhip_gridder_info {
     size_t device_bytes;   /* device memory held by the handle                */
     /* plane transform: bit 0 = hand-written row FFT on the first axis (else rocFFT); bit 1 = second axis fused
      * with pad / crop / w-screen (sizes {1,3,5,7,9,15} x 2^a in 1024..16384); bit 2 = second axis on the hand-written
-     * FFT with separate pad / crop kernels (the doubled sizes 20480, 24576); neither bit 1 nor 2: rocFFT */
+     * FFT with separate pad / crop kernels (the doubled sizes 20480, 24576); neither bit 1 nor 2: rocFFT; bit 3 = first
+     * axis with the crop / pad + transpose folded into the transform (no separate transpose kernels) */
     int32_t fft_mode;
     int32_t screen_poly;   /* coefficients of the n-1 polynomial of the fused w-screen (0: closed form) */
-    /* scatter kernel: 1 = register-footprint form (k_grid_blk: visibilities sorted by tile and 4 x 4-cell block, LDS
-     * atomics only when the block changes), 0 = diagonal-walk form (k_grid_mp: LDS atomics per tap) */
+    /* scatter kernel: 2 = record-driven register-footprint form (k_grid_rec), 1 = register-footprint form (k_grid_blk:
+     * visibilities sorted by tile and 4 x 4-cell block, LDS atomics only when the block changes), 0 = diagonal-walk form
+     * (k_grid_mp: LDS atomics per tap) */
     int32_t scatter_mode;
     /* launches of the scatter per pass over the planes: 4 = one per tile colour (tile-row / tile-column parity), whose
      * tile flush is a plain read-add-write because no two tiles of a colour overlap; 1 = one launch, atomic flush */
     int32_t scatter_launches;
+    /* cells of one uv-plane the scatter / gather can touch (tiles with visibilities + halo); the first-axis transforms and
+     * the Hessian's plane clear move only these of the occupied rows (0: not computed, every cell of the occupied rows) */
+    int64_t used_cells;
 } pfbhip_gridder_info;
 
 int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw_host /* (nrow,3) */,

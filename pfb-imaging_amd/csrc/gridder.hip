@@ -1665,9 +1665,17 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
                 else if (rr.empty()) runs_t[size_t(tu)] = make_int4(0, 0, 0, 0);
                 // (three or more runs: the whole row)
             }
+            info.used_cells = 0;
+            for (int64_t tu = 0; tu < ntu_t; ++tu) {
+                const int4 r = runs_t[size_t(tu)];
+                info.used_cells += std::min<int64_t>(TILE, info.nu - tu * TILE) * (int64_t(r.y - r.x) + int64_t(r.w - r.z));
+            }
         }
         if (std::getenv("PFBHIP_COLRUNS") != nullptr && std::getenv("PFBHIP_COLRUNS")[0] == '0')
+        {
             std::fill(runs_t.begin(), runs_t.end(), make_int4(0, int(info.nv), 0, 0));
+            info.used_cells = 0;
+        }
         g->d_colruns.alloc(runs_t.size());
         PFB_HIP(hipMemcpyAsync(g->d_colruns.p, runs_t.data(), runs_t.size() * sizeof(int4), hipMemcpyHostToDevice, st));
         PFB_HIP(hipStreamSynchronize(st));
