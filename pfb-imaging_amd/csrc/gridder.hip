@@ -1789,6 +1789,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             PFB_HIP(hipStreamSynchronize(st));
         }
         if (!g->tfft) g->fgeom.tpitch = 0;  // (the tile-transpose kernels read B[y][u])
+        if (!g->tfft) g->n_clear_rects = 0;  // (the plain first-axis transform runs IN PLACE on the scatter's planes: whole rows to clear)
         info.fft_mode |= g->tfft ? 8 : 0;
     }
     if (any_rocfft) {

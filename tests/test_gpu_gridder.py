@@ -440,8 +440,10 @@ def test_first_axis_variants_agree(monkeypatch):
     c["cell"] = c["cell"] * 64.0 / 1100
     c["x"] = rng.standard_normal((1100, 1000))
     outs = []
-    for env in ({}, {"PFBHIP_TPAD": "0"}, {"PFBHIP_TFFT": "2"}, {"PFBHIP_TFFT": "0"}):
-        for k in ("PFBHIP_TPAD", "PFBHIP_TFFT"):
+    # (+ the whole-row forms of what is pruned to the used cells of a plane: first-axis loads / stores, the Hessian's clear)
+    for env in ({}, {"PFBHIP_TPAD": "0"}, {"PFBHIP_TFFT": "2"}, {"PFBHIP_TFFT": "0"}, {"PFBHIP_COLRUNS": "0"},
+                {"PFBHIP_ASYNC_CLEAR": "0"}):
+        for k in ("PFBHIP_TPAD", "PFBHIP_TFFT", "PFBHIP_COLRUNS", "PFBHIP_ASYNC_CLEAR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -449,8 +451,14 @@ def test_first_axis_variants_agree(monkeypatch):
         assert g.info["fft_mode"] & 3 == 3
         assert bool(g.info["fft_mode"] & 8) == (env.get("PFBHIP_TFFT") != "0")
         g.set_weights(c["wgt"])
-        outs.append((g.vis2dirty(c["vis"], c["wgt"]), g.dirty2vis(c["x"]), g.hessian(c["x"])))
+        h1 = g.hessian(c["x"])
+        # a second apply on the same handle sees planes the first one left behind (only their used cells are cleared)
+        h2 = g.hessian(2.0 * c["x"])
+        assert rel(h2, 2.0 * h1) < 1e-11
+        outs.append((g.vis2dirty(c["vis"], c["wgt"]), g.dirty2vis(c["x"]), h1))
         g.close()
+    for k in ("PFBHIP_COLRUNS", "PFBHIP_ASYNC_CLEAR"):
+        monkeypatch.delenv(k, raising=False)
     for d, v, h in outs[1:]:
         assert rel(d, outs[0][0]) < 1e-11 and rel(v, outs[0][1]) < 1e-11 and rel(h, outs[0][2]) < 1e-11  # (LDS atomics: run-to-run 1e-13)
 
