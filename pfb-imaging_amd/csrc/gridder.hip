@@ -1385,8 +1385,9 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     // Small plans (C1: ~300 work items) run faster on the single-launch walk kernel: four colour launches of a few dozen
     // workgroups each leave most of the 256 CUs idle.  The block order of the sort is kept either way (any order is valid).
     {
-        size_t per_pass = work.size();
-        for (size_t c : g->work_cnt) per_pass = std::min(per_pass, c);
+        // (mean over the passes: the first and last pass of an ES-plane plan hold the few visibilities at the ends of the w
+        // range -- their launches are short whichever kernel runs them)
+        const size_t per_pass = work.size() / std::max<size_t>(g->work_cnt.size(), 1);
         if (g->scatter_blk && smode != "block" && smode != "rec" && per_pass < size_t(2048)) g->scatter_blk = false;
     }
     {
