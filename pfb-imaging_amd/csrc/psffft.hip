@@ -72,12 +72,22 @@ struct PsfPadLoad2 {
     }
 };
 
+// Transposed stores (passes 1 and 2 write the layout the next pass reads row-wise; no transpose kernels): the 16-byte
+// pieces of a 128-byte line of the destination come from 8 consecutive source rows, which this map hands to 8 workgroups
+// of ONE XCD (block ids equal mod 8) inside the same 64 block ids -- the line leaves that XCD's L2 whole.
+__device__ __forceinline__ int psf_xcd_row(int b, int n)
+{
+    if (b >= (n & ~63)) return b;
+    const int r = b & 63;
+    return (b & ~63) + (r & 7) * 8 + (r >> 3);
+}
+
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_rows_fwd(const double2 *tw, const double *x, const double *beam,
-                                                                          int nx, int ny, double2 *t1, size_t ld1)
+                                                                          int nx, int ny, double2 *t2, size_t ld2)
 {
     extern __shared__ double rf_lds[];
-    const size_t r0 = size_t(blockIdx.x) * 2;
+    const size_t r0 = size_t(psf_xcd_row(int(blockIdx.x), (nx + 1) / 2)) * 2;  // (4 row pairs = 8 rows = one line of T2)
     const bool two = r0 + 1 < size_t(nx);
     PsfPadLoad2 ld{x + r0 * size_t(ny), two ? x + (r0 + 1) * size_t(ny) : nullptr,
                    beam != nullptr ? beam + r0 * size_t(ny) : nullptr,
@@ -100,13 +110,15 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_rows_fwd(const 
     rf_barrier();
 #pragma unroll
     for (int e = 0; e < S::E; ++e) pim[e] = rf_lds[rf_swz(rf_neg_index<S>(S::out_pos(t, e)))];
-    double2 *rowa = t1 + r0 * ld1, *rowb = rowa + ld1;
+    // T2[k][r0], T2[k][r0 + 1]: 32 contiguous bytes per frequency
+    double2 *col = t2 + r0;
 #pragma unroll
     for (int e = 0; e < S::E; ++e) {
         const int k = S::out_pos(t, e);
         if (k <= S::N / 2) {
-            rowa[k] = make_double2(0.5 * (re[e] + pre[e]), 0.5 * (im[e] - pim[e]));
-            if (two) rowb[k] = make_double2(0.5 * (im[e] + pim[e]), 0.5 * (pre[e] - re[e]));
+            double2 *o = col + size_t(k) * ld2;
+            o[0] = make_double2(0.5 * (re[e] + pre[e]), 0.5 * (im[e] - pim[e]));
+            if (two) o[1] = make_double2(0.5 * (im[e] + pim[e]), 0.5 * (pre[e] - re[e]));
         }
     }
 }
@@ -130,12 +142,13 @@ struct PsfLdsLoad {
 
 // mode 0: psf, 1: psf + shift, 2: 1 / (psf + shift); norm = 1 / (nxp nyp) folded in
 template <class S>
-__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_cols(const double2 *tw, double2 *t2, int nx, const double *psfT,
-                                                                      int is_complex, int mode, double shift, double norm)
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_cols(const double2 *tw, const double2 *t2, size_t ld2, int nx, int nyo2,
+                                                                      const double *psfT, int is_complex, int mode, double shift,
+                                                                      double norm, double2 *t1, size_t ld1)
 {
     extern __shared__ double rf_lds[];
-    const size_t k = blockIdx.x;
-    double2 *row = t2 + k * size_t(nx);
+    const size_t k = size_t(psf_xcd_row(int(blockIdx.x), nyo2));
+    const double2 *row = t2 + k * ld2;
     PsfColLoad ld{row, nx};
     double re[S::E], im[S::E];
     int t;
@@ -205,7 +218,7 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_psf_cols(const doub
 #pragma unroll
     for (int e = 0; e < S::E; ++e) {
         const int p = S::out_pos(tb, e);
-        if (p < nx) row[p] = make_double2(im2[e], re2[e]);
+        if (p < nx) t1[size_t(p) * ld1 + k] = make_double2(im2[e], re2[e]);  // T1[p][k]: pass 3 reads rows of T1
     }
 }
 
@@ -282,7 +295,8 @@ bool PsfFFT::init(int64_t nx_, int64_t ny_, int64_t nxp_, int64_t nyp_)
     ld1 = size_t(ceil_div(nyo2, 32) * 32);
     if (!fy.init(nyp) || !fx.init(nxp)) return false;
     t1.alloc(size_t(nx) * ld1);
-    t2.alloc(size_t(nyo2) * size_t(nx));
+    ld2 = size_t(nx) + 8;  // (off the power of two: the transposed stores of pass 1 walk the rows of T2)
+    t2.alloc(size_t(nyo2) * ld2);
     ok = true;
     return true;
 }
@@ -302,15 +316,16 @@ static void launch_rows_fwd(const PsfFFT &p, const double *x, const double *beam
     static bool attr = false;
     psf_allow_lds(&k_psf_rows_fwd<S>, &attr);
     hipLaunchKernelGGL(k_psf_rows_fwd<S>, dim3(uint32_t((p.nx + 1) / 2)), dim3(S::T), size_t(S::LDS_BYTES), st, p.fy.pl.twiddle,
-                       x, beam, int(p.nx), int(p.ny), p.t1.p, p.ld1);
+                       x, beam, int(p.nx), int(p.ny), p.t2.p, p.ld2);
 }
 template <class S>
 static void launch_cols(const PsfFFT &p, const double *psfT, bool is_complex, int mode, double shift, hipStream_t st)
 {
     static bool attr = false;
     psf_allow_lds(&k_psf_cols<S>, &attr);
-    hipLaunchKernelGGL(k_psf_cols<S>, dim3(uint32_t(p.nyo2)), dim3(S::T), size_t(S::LDS_BYTES), st, p.fx.pl.twiddle, p.t2.p,
-                       int(p.nx), psfT, is_complex ? 1 : 0, mode, shift, 1.0 / (double(p.nxp) * double(p.nyp)));
+    hipLaunchKernelGGL(k_psf_cols<S>, dim3(uint32_t(p.nyo2)), dim3(S::T), size_t(S::LDS_BYTES), st, p.fx.pl.twiddle, p.t2.p, p.ld2,
+                       int(p.nx), int(p.nyo2), psfT, is_complex ? 1 : 0, mode, shift, 1.0 / (double(p.nxp) * double(p.nyp)), p.t1.p,
+                       p.ld1);
 }
 template <class S>
 static void launch_rows_inv(const PsfFFT &p, const double *beam, const double *x, double scale, double eta, int accumulate,
@@ -334,7 +349,6 @@ void PsfFFT::apply(const double *x_dev, const double *beam_dev, const double *ps
         default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nyp);
     }
     PFB_HIP(hipGetLastError());
-    transpose_any(t1.p, nx, nyo2, ld1, t2.p, size_t(nx), st);
     switch (nxp) {
 #define RF_X(L, K) \
     case (L << K): launch_cols<PsfShape<L, K>>(*this, psfT_dev, is_complex, mode, shift, st); break;
@@ -343,7 +357,6 @@ void PsfFFT::apply(const double *x_dev, const double *beam_dev, const double *ps
         default: PFB_REQUIRE(false, "unsupported padded size %lld", (long long)nxp);
     }
     PFB_HIP(hipGetLastError());
-    transpose_any(t2.p, nyo2, nx, size_t(nx), t1.p, ld1, st);
     switch (nyp) {
 #define RF_X(L, K) \
     case (L << K): launch_rows_inv<PsfShape<L, K>>(*this, beam_dev, x_dev, scale, eta, accumulate, out_dev, st); break;

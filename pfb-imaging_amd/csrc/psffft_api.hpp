@@ -25,6 +25,7 @@ struct PsfFFT {
     bool ok = false;
     int64_t nx = 0, ny = 0, nxp = 0, nyp = 0, nyo2 = 0;
     size_t ld1 = 0;  // row stride of T1 (complex elements)
+    size_t ld2 = 0;  // row stride of T2
     RowFFT fy, fx;
     DevBuf<double2> t1, t2;
     bool init(int64_t nx, int64_t ny, int64_t nxp, int64_t nyp);
