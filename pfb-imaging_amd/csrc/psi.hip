@@ -93,39 +93,52 @@ __global__ void __launch_bounds__(256) k_dwt_cols(const double *__restrict__ in,
 // cb[t][c] = sum_q lo[2q+p] blk[m+h-1-q][c] + hi[2q+p] blk[s0+m+h-1-q][c],  t = 2m+p < n0out, c < ncol.
 // The LL quadrant (rows < s0, columns < sll) is read from `ll` (the reconstruction of the level below)
 // when ll != NULL, so that the caller's coefficient array is never written.
+// One thread produces BOTH output rows 2m and 2m + 1 of its column from the same h input pairs (blockIdx.y = m).
 __global__ void __launch_bounds__(256) k_idwt_cols(const double *__restrict__ blk, size_t ldb, int s0, int ncol, Filt f,
                                                     const double *__restrict__ ll, size_t ldl, int sll, int n0out,
                                                     double *__restrict__ cb, size_t ldc)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const int t = blockIdx.y;
+    const int m = blockIdx.y;
     if (c >= ncol) return;
-    const int m = t >> 1, p = t & 1, h = f.L / 2;
+    const int h = f.L / 2;
     const bool from_ll = ll != nullptr && c < sll;
-    double acc = 0.0;
+    double a0 = 0.0, a1 = 0.0;
     for (int q = 0; q < h; ++q) {
         const int r = m + h - 1 - q;
         const double lo = from_ll ? ll[size_t(r) * ldl + size_t(c)] : blk[size_t(r) * ldb + size_t(c)];
-        acc += f.lo[2 * q + p] * lo + f.hi[2 * q + p] * blk[size_t(s0 + r) * ldb + size_t(c)];
+        const double hi = blk[size_t(s0 + r) * ldb + size_t(c)];
+        a0 += f.lo[2 * q] * lo + f.hi[2 * q] * hi;
+        a1 += f.lo[2 * q + 1] * lo + f.hi[2 * q + 1] * hi;
     }
-    cb[size_t(t) * ldc + size_t(c)] = acc;
+    cb[size_t(2 * m) * ldc + size_t(c)] = a0;
+    if (2 * m + 1 < n0out) cb[size_t(2 * m + 1) * ldc + size_t(c)] = a1;
 }
 
 // img[i][u] (=|+=) sum_q lo[2q+p] cb[i][m+h-1-q] + hi[2q+p] cb[i][s1+m+h-1-q],  u = 2m+p < n1out
+// One thread produces the output pair u = 2m, 2m + 1 (one 16-byte store when the row pitch allows it).
 __global__ void __launch_bounds__(256) k_idwt_rows(const double *__restrict__ cb, size_t ldc, int s1, Filt f, int n1out,
                                                     int accumulate, double *__restrict__ img, size_t ldi)
 {
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= n1out) return;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (2 * m >= n1out) return;
     const double *row = cb + size_t(blockIdx.y) * ldc;
-    const int m = u >> 1, p = u & 1, h = f.L / 2;
-    double acc = 0.0;
+    const int h = f.L / 2;
+    double a0 = 0.0, a1 = 0.0;
     for (int q = 0; q < h; ++q) {
         const int r = m + h - 1 - q;
-        acc += f.lo[2 * q + p] * row[r] + f.hi[2 * q + p] * row[s1 + r];
+        const double lo = row[r], hi = row[s1 + r];
+        a0 += f.lo[2 * q] * lo + f.hi[2 * q] * hi;
+        a1 += f.lo[2 * q + 1] * lo + f.hi[2 * q + 1] * hi;
     }
-    double *o = img + size_t(blockIdx.y) * ldi + size_t(u);
-    *o = accumulate ? *o + acc : acc;
+    double *o = img + size_t(blockIdx.y) * ldi + size_t(2 * m);
+    if (accumulate) {
+        o[0] += a0;
+        if (2 * m + 1 < n1out) o[1] += a1;
+    } else {
+        o[0] = a0;
+        if (2 * m + 1 < n1out) o[1] = a1;
+    }
 }
 
 // dst (rows x cols, ldd) (=|+=) src (lds)
@@ -353,16 +366,16 @@ struct pfbhip_psi {
                 const bool deepest = i == nlevel - 1;
                 const size_t ldc = size_t(2 * sy);
                 // the level below left its reconstruction in img (ld = ny); it replaces this level's LL quadrant
-                hipLaunchKernelGGL(k_idwt_cols, grid2(2 * sy, nxo), dim3(256), 0, stream, blk, size_t(nymax), int(sx), int(2 * sy),
+                hipLaunchKernelGGL(k_idwt_cols, grid2(2 * sy, (nxo + 1) / 2), dim3(256), 0, stream, blk, size_t(nymax), int(sx), int(2 * sy),
                                    w.rec, deepest ? static_cast<const double *>(nullptr) : img2(), size_t(ny), int(sy), int(nxo),
                                    cbuff.p, ldc);
                 if (i > 0) {
                     // img and img2 alternate so that a level never reads the buffer it writes
                     swap_img();
-                    hipLaunchKernelGGL(k_idwt_rows, grid2(nyo, nxo), dim3(256), 0, stream, cbuff.p, ldc, int(sy), w.rec, int(nyo), 0,
+                    hipLaunchKernelGGL(k_idwt_rows, grid2((nyo + 1) / 2, nxo), dim3(256), 0, stream, cbuff.p, ldc, int(sy), w.rec, int(nyo), 0,
                                        img2(), size_t(ny));
                 } else {
-                    hipLaunchKernelGGL(k_idwt_rows, grid2(nyo, nxo), dim3(256), 0, stream, cbuff.p, ldc, int(sy), w.rec, int(nyo),
+                    hipLaunchKernelGGL(k_idwt_rows, grid2((nyo + 1) / 2, nxo), dim3(256), 0, stream, cbuff.p, ldc, int(sy), w.rec, int(nyo),
                                        first ? 0 : 1, x, size_t(ny));
                 }
             }
