@@ -44,6 +44,38 @@ __global__ void __launch_bounds__(256) k_pd_primal(double *__restrict__ x, const
     const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
     if (i < n) x[i] = xp[i] - tau * xout[i];
 }
+// Primal step, positivity and the three norms in ONE pass over the images (all bands of a pixel in the same thread):
+// x = xp - tau xout ; mode 1: clamp negatives, mode 2: zero the pixel in every band where any band is <= 0
+// (positivity.py:12-33) ; partials [0] = |x - xp|^2, [1] = |x|^2, [2] = #nonzero(x).  nband <= PD_MAXB.
+constexpr int PD_MAXB = 16;
+static __global__ void __launch_bounds__(CG_THREADS) k_pd_step(int64_t npix, int nband, double *__restrict__ x,
+                                                                const double *__restrict__ xp, const double *__restrict__ xout,
+                                                                double tau, int mode, double *partials)
+{
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = blockIdx.x * int64_t(CG_THREADS) + threadIdx.x; i < npix; i += int64_t(CG_BLOCKS) * CG_THREADS) {
+        double xs[PD_MAXB], ps[PD_MAXB];
+        bool bad = false;
+        for (int b = 0; b < nband; ++b) {
+            const size_t o = size_t(b) * size_t(npix) + size_t(i);
+            ps[b] = xp[o];
+            xs[b] = ps[b] - tau * xout[o];
+            bad = bad || xs[b] <= 0.0;
+        }
+        for (int b = 0; b < nband; ++b) {
+            double xi = xs[b];
+            if (mode == 1 && xi < 0.0) xi = 0.0;
+            if (mode == 2 && bad) xi = 0.0;
+            x[size_t(b) * size_t(npix) + size_t(i)] = xi;
+            const double d = xi - ps[b];
+            v[0] += d * d;
+            v[1] += xi * xi;
+            v[2] += (xi != 0.0) ? 1.0 : 0.0;
+        }
+    }
+    block_reduce_store<3>(v, partials);
+}
+
 // partials [0] = |x - xp|^2, [1] = |x|^2, [2] = #nonzero(x)
 static __global__ void __launch_bounds__(CG_THREADS) k_pd_norms(int64_t n, const double *x, const double *xp, double *partials)
 {
@@ -150,16 +182,22 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
                     psfconv_apply_async(pcs[b], d.p, psf_slots[q], beam_slots[q], 0, 0.0, -scale[b] / gamma,
                                         q == off[size_t(b)] ? -eta[b] / gamma : 0.0, 1, xo);
             }
-            hipLaunchKernelGGL(k_pd_primal, blocks(nimg), dim3(256), 0, st, x, xp, xout.p, tau, int64_t(nimg));
-            if (positivity == 2 && comm != nullptr) {  // "any band <= 0" spans the ranks
-                positivity_flag_async(x, nband, int64_t(npix), d.p, st);
-                PFB_HIP(hipStreamSynchronize(st));
-                PFB_CHECK_STATUS(pfbhip_comm_allreduce_sum(comm, d.p, d.p, int64_t(npix)));
-                positivity_zero_async(x, nband, int64_t(npix), d.p, st);
-            } else if (positivity) {
-                positivity_async(x, nband, int64_t(npix), positivity, st);
+            const bool one_pass = !(positivity == 2 && comm != nullptr) && nband <= PD_MAXB;
+            if (one_pass) {
+                hipLaunchKernelGGL(k_pd_step, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, st, int64_t(npix), int(nband), x, xp, xout.p, tau,
+                                   positivity, partials.p);
+            } else {
+                hipLaunchKernelGGL(k_pd_primal, blocks(nimg), dim3(256), 0, st, x, xp, xout.p, tau, int64_t(nimg));
+                if (positivity == 2 && comm != nullptr) {  // "any band <= 0" spans the ranks
+                    positivity_flag_async(x, nband, int64_t(npix), d.p, st);
+                    PFB_HIP(hipStreamSynchronize(st));
+                    PFB_CHECK_STATUS(pfbhip_comm_allreduce_sum(comm, d.p, d.p, int64_t(npix)));
+                    positivity_zero_async(x, nband, int64_t(npix), d.p, st);
+                } else if (positivity) {
+                    positivity_async(x, nband, int64_t(npix), positivity, st);
+                }
+                hipLaunchKernelGGL(k_pd_norms, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, st, int64_t(nimg), x, xp, partials.p);
             }
-            hipLaunchKernelGGL(k_pd_norms, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, st, int64_t(nimg), x, xp, partials.p);
             PFB_HIP(hipGetLastError());
             PFB_HIP(hipMemcpyAsync(hpart.data(), partials.p, hpart.size() * sizeof(double), hipMemcpyDeviceToHost, st));
             PFB_HIP(hipStreamSynchronize(st));
