@@ -152,6 +152,20 @@ __global__ void __launch_bounds__(256) k_copy2d(const double *__restrict__ src, 
     *o = accumulate ? *o + v : v;
 }
 
+// Zero the rectangles {slice, row0, nrows, col0, ncols} of a coefficient cube (slices of nxmax x nymax doubles): the cells
+// of alpha no transform writes (margins of the packed Mallat layout, padding up to the largest basis).
+struct ZeroRect {
+    int slice, row0, nrows, col0, ncols;
+};
+__global__ void __launch_bounds__(256) k_zero_rects(const ZeroRect *__restrict__ rects, double *__restrict__ alpha, size_t slice_stride,
+                                                     size_t ld)
+{
+    const ZeroRect r = rects[blockIdx.x];
+    double *base = alpha + size_t(r.slice) * slice_stride + size_t(r.row0) * ld + size_t(r.col0);
+    const int64_t n = int64_t(r.nrows) * r.ncols;
+    for (int64_t i = threadIdx.x; i < n; i += 256) base[size_t(i / r.ncols) * ld + size_t(i % r.ncols)] = 0.0;
+}
+
 // out (cols, rows) = in (rows, cols)^T
 __global__ void __launch_bounds__(256) k_transpose_f64_any(const double *__restrict__ in, int rows, int cols,
                                                             double *__restrict__ out)
@@ -307,6 +321,8 @@ struct pfbhip_psi {
     std::vector<Wav> wav;  // one per basis (unused for self)
     hipStream_t stream = nullptr;
     DevBuf<double> cbuff, img, d_x, d_alpha, d_alphaT;
+    DevBuf<ZeroRect> d_zero;  // what dot() has to zero itself: everything else of alpha is written by a transform
+    int n_zero = 0;
     ~pfbhip_psi()
     {
         if (stream) (void)hipStreamDestroy(stream);
@@ -316,7 +332,9 @@ struct pfbhip_psi {
     // alpha (nbasis, nxmax, nymax) <- x (nx, ny); every element of alpha is written
     void dot(const double *x, double *alpha)
     {
-        PFB_HIP(hipMemsetAsync(alpha, 0, cube() * sizeof(double), stream));
+        if (n_zero > 0)
+            hipLaunchKernelGGL(k_zero_rects, dim3(uint32_t(n_zero)), dim3(256), 0, stream, d_zero.p, alpha, size_t(nxmax) * size_t(nymax),
+                               size_t(nymax));
         for (int b = 0; b < nbasis; ++b) {
             double *ab = alpha + size_t(b) * size_t(nxmax) * size_t(nymax);
             if (bases[size_t(b)] == 0) {
@@ -517,6 +535,43 @@ int pfbhip_psi_create(int64_t nx, int64_t ny, int32_t nbasis, const int32_t *bas
         }
         p->nxmax = nxmax;
         p->nymax = nymax;
+        {   // complement of the written rectangles per slice, on the grid of their boundaries; long rectangles are cut into
+            // slabs of 64 rows so that a workgroup's share stays small
+            std::vector<ZeroRect> zr;
+            for (int b = 0; b < nbasis; ++b) {
+                struct R { int64_t x0, x1, y0, y1; };
+                std::vector<R> written;
+                if (bases[b] == 0) {
+                    written.push_back({0, nx, 0, ny});
+                } else {
+                    const auto &w = p->wav[size_t(b)];
+                    for (int k = 0; k < nlevel; ++k)
+                        written.push_back({w.hx[size_t(k)] - 2 * w.sx[size_t(k)], w.hx[size_t(k)], w.hy[size_t(k)] - 2 * w.sy[size_t(k)],
+                                           w.hy[size_t(k)]});
+                }
+                std::vector<int64_t> xs{0, nxmax}, ys{0, nymax};
+                for (auto &r : written) {
+                    xs.push_back(r.x0); xs.push_back(r.x1); ys.push_back(r.y0); ys.push_back(r.y1);
+                }
+                std::sort(xs.begin(), xs.end()); xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
+                std::sort(ys.begin(), ys.end()); ys.erase(std::unique(ys.begin(), ys.end()), ys.end());
+                for (size_t i = 0; i + 1 < xs.size(); ++i)
+                    for (size_t j = 0; j + 1 < ys.size(); ++j) {
+                        if (xs[i] < 0 || xs[i + 1] > nxmax || ys[j] < 0 || ys[j + 1] > nymax) continue;
+                        bool covered = false;
+                        for (auto &r : written)
+                            covered = covered || (xs[i] >= r.x0 && xs[i + 1] <= r.x1 && ys[j] >= r.y0 && ys[j + 1] <= r.y1);
+                        if (covered) continue;
+                        for (int64_t r0 = xs[i]; r0 < xs[i + 1]; r0 += 64)
+                            zr.push_back({b, int(r0), int(std::min<int64_t>(64, xs[i + 1] - r0)), int(ys[j]), int(ys[j + 1] - ys[j])});
+                    }
+            }
+            p->n_zero = int(zr.size());
+            if (!zr.empty()) {
+                p->d_zero.alloc(zr.size());
+                PFB_HIP(hipMemcpy(p->d_zero.p, zr.data(), zr.size() * sizeof(ZeroRect), hipMemcpyHostToDevice));
+            }
+        }
         PFB_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         p->cbuff.alloc(size_t(nxmax) * size_t(2 * std::max<int64_t>(symax, 1)));
         p->img.alloc(size_t(nx) * size_t(ny));

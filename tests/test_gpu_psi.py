@@ -56,6 +56,35 @@ def test_psi_dot_hdot_vs_oracle(bases, nlevel, shape):
     assert rel(xt, xo) < 1e-15
 
 
+@pytest.mark.parametrize("bases,nlevel,shape", [
+    (("self", "db1", "db2", "db3"), 3, (128, 96)),
+    (("db8", "self", "db6"), 3, (250, 300)),
+    (("db4",), 2, (64, 512)),
+])
+def test_psi_dot_writes_every_coefficient_of_a_dirty_device_cube(bases, nlevel, shape):
+    """dot() zeroes only the cells no transform writes (margins of the packed layout, padding up to the largest basis): a
+    device cube full of NaN must come back exactly as the oracle's, zeros included."""
+    import ctypes as ct
+
+    from pfb_imaging_amd._lib import DeviceArray, check, lib
+    from pfb_imaging_amd.operators.psi import PsiBand
+
+    nx, ny = shape
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((1, nx, ny))
+    o = opsi.Psi(1, nx, ny, bases, nlevel)
+    a_ref = np.zeros((1, o.nbasis, o.nxmax, o.nymax))
+    o.dot(x, a_ref)
+    g = PsiBand(nx, ny, bases, nlevel)
+    xd = DeviceArray.from_host(x[0])
+    ad = DeviceArray.from_host(np.full((o.nbasis, o.nxmax, o.nymax), np.nan))
+    check(lib().pfbhip_psi_dot_dev(g._h, xd.ptr, ad.ptr))
+    a = ad.download()
+    assert not np.isnan(a).any()
+    assert np.array_equal(a == 0.0, a_ref[0] == 0.0)
+    assert rel(a, a_ref[0]) < 1e-14
+
+
 def test_psi_errors():
     from pfb_imaging_amd.operators.psi import PsiNocopyt
 
