@@ -117,8 +117,11 @@ __global__ void __launch_bounds__(256) k_idwt_cols(const double *__restrict__ bl
 
 // img[i][u] (=|+=) sum_q lo[2q+p] cb[i][m+h-1-q] + hi[2q+p] cb[i][s1+m+h-1-q],  u = 2m+p < n1out
 // One thread produces the output pair u = 2m, 2m + 1 (one 16-byte store when the row pitch allows it).
+// `extra` (ld = lde; NULL: none) is added on top when not accumulating: the identity basis' slice of the cube, which then
+// needs no pass of its own over the image.
 __global__ void __launch_bounds__(256) k_idwt_rows(const double *__restrict__ cb, size_t ldc, int s1, Filt f, int n1out,
-                                                    int accumulate, double *__restrict__ img, size_t ldi)
+                                                    int accumulate, double *__restrict__ img, size_t ldi,
+                                                    const double *__restrict__ extra, size_t lde)
 {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (2 * m >= n1out) return;
@@ -136,6 +139,11 @@ __global__ void __launch_bounds__(256) k_idwt_rows(const double *__restrict__ cb
         o[0] += a0;
         if (2 * m + 1 < n1out) o[1] += a1;
     } else {
+        if (extra != nullptr) {
+            const double *x = extra + size_t(blockIdx.y) * lde + size_t(2 * m);
+            a0 += x[0];
+            if (2 * m + 1 < n1out) a1 += x[1];
+        }
         o[0] = a0;
         if (2 * m + 1 < n1out) o[1] = a1;
     }
@@ -367,9 +375,18 @@ struct pfbhip_psi {
     void hdot(const double *alpha, double *x)
     {
         bool first = true;
+        // the identity basis rides on the first wavelet basis' last row pass (if there is a wavelet basis)
+        const double *ident = nullptr;
+        bool any_wavelet = false;
+        for (int b = 0; b < nbasis; ++b) {
+            if (bases[size_t(b)] == 0 && ident == nullptr) ident = alpha + size_t(b) * size_t(nxmax) * size_t(nymax);
+            any_wavelet = any_wavelet || bases[size_t(b)] != 0;
+        }
+        const double *ident_used = any_wavelet ? ident : nullptr;
         for (int b = 0; b < nbasis; ++b) {
             const double *ab = alpha + size_t(b) * size_t(nxmax) * size_t(nymax);
             if (bases[size_t(b)] == 0) {
+                if (ab == ident_used) continue;  // (added by the first wavelet basis below)
                 hipLaunchKernelGGL(k_copy2d, grid2(ny, nx), dim3(256), 0, stream, ab, size_t(nymax), int(ny), first ? 0 : 1, x,
                                    size_t(ny));
                 first = false;
@@ -391,10 +408,12 @@ struct pfbhip_psi {
                     // img and img2 alternate so that a level never reads the buffer it writes
                     swap_img();
                     hipLaunchKernelGGL(k_idwt_rows, grid2((nyo + 1) / 2, nxo), dim3(256), 0, stream, cbuff.p, ldc, int(sy), w.rec, int(nyo), 0,
-                                       img2(), size_t(ny));
+                                       img2(), size_t(ny), static_cast<const double *>(nullptr), size_t(0));
                 } else {
+                    // (nxo == nx, nyo == ny at level 0: the pass covers the image)
                     hipLaunchKernelGGL(k_idwt_rows, grid2((nyo + 1) / 2, nxo), dim3(256), 0, stream, cbuff.p, ldc, int(sy), w.rec, int(nyo),
-                                       first ? 0 : 1, x, size_t(ny));
+                                       first ? 0 : 1, x, size_t(ny), first ? ident_used : static_cast<const double *>(nullptr),
+                                       size_t(nymax));
                 }
             }
             first = false;
