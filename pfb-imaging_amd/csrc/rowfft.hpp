@@ -336,12 +336,13 @@ __device__ __forceinline__ void rf_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // j = t + i T, i.e. position expand(j) + dft_index<R>(s) Ns; afterwards slot e holds position t + e T.
 // The row moves one component at a time (N doubles of LDS) or, DUAL, both at once (2 N doubles, half
 // the barriers).
-template <int R, int E, bool DUAL, bool SWZ, int T, int N, int Ns, int PAD>
+template <int R, int E, bool DUAL, bool SWZ, int T, int N, int Ns, int PAD, int NL>
 __device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], int t, double *lds)
 {
     constexpr int IT = E / R;
     static_assert(T % Ns == 0, "the butterfly's offset within its sub-transform must not depend on i");
-    static_assert(PAD == 0 || (!SWZ && !DUAL && T % (R * Ns) == 0), "padded exchange: natural layout, one component, whole blocks per e");
+    static_assert(PAD == 0 || (!SWZ && T % (R * Ns) == 0), "padded exchange: natural layout, whole blocks per e");
+    static_assert(NL >= N + PAD * (N / (R * Ns)), "component length of the LDS buffer");
     // write position of slot i + s IT (recomputed per component: E address registers are worth more
     // than E integer operations): one base per thread plus compile-time offsets.
     // PAD > 0: every block of R Ns positions (one butterfly group a = t / Ns) is followed by PAD unused doubles.  In the
@@ -354,7 +355,7 @@ __device__ __forceinline__ void rf_transpose(double (&re)[E], double (&im)[E], i
     const int r0 = PAD > 0 ? t + PAD * (t / (R * Ns)) : t;
     constexpr int RS = PAD > 0 ? T + PAD * (T / (R * Ns)) : T;  // reader's step per slot
     if (DUAL) {
-        double *l2 = lds + N;
+        double *l2 = lds + NL;
 #pragma unroll
         for (int i = 0; i < IT; ++i)
 #pragma unroll
@@ -449,13 +450,13 @@ struct rf_load_from_lds<Load, std::void_t<decltype(Load::FROM_LDS)>> : std::bool
 
 // Leading odd pass (radix M = 3 or 5, Ns = 1): N/M butterflies, ceil(E/M) per thread, inputs read
 // straight from the load functor, outputs written straight into the LDS transpose.
-template <int M, int E, bool DUAL, bool SWZ, int T, int N, class Load>
+template <int M, int E, bool DUAL, bool SWZ, int T, int N, int NL, class Load>
 __device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], int t, Load &ld, bool inverse, double *lds)
 {
     constexpr int IT = (E + M - 1) / M;
     constexpr bool PRE = rf_load_from_lds<Load>::value;
     const int nbf = N / M;
-    double *l2 = lds + N;
+    double *l2 = lds + NL;
     double oim[DUAL ? 1 : IT * M];
     double2 vin[PRE ? IT * M : 1];
     if constexpr (PRE) {
@@ -525,7 +526,11 @@ struct RfShape {
     static constexpr bool DOUBLED = false;
     static constexpr int NSLOT = LEAD_ > 1 ? ((E + LEAD_ - 1) / LEAD_) * LEAD_ : E;  // load-functor slots per row
     static constexpr int NP = rf_npass(K_);
-    static constexpr bool SWZ = LEAD_ == 1;  // LDS layout of the exchanges (see rf_pos)
+    // LDS layout of the exchanges (see rf_pos / rf_transpose).  Power-of-two shapes from 4096 points take the natural layout
+    // too, PADDED per exchange: one spare double per 16 positions in the first exchange (writes of stride 16 -> 17) and 16 per
+    // 256 in the second (the 16-lane groups of a write land 256 apart -> 272); both need N / 16 spare doubles per component.
+    // Smaller ones (T not a multiple of 256) keep the xor swizzle.
+    static constexpr bool SWZ = LEAD_ == 1 && (N < 4096 || E_ > 16);
     static constexpr int RLAST = rf_radix(K_, NP - 1);
     // Two workgroups per CU where they fit (LDS: 2 x N doubles when the row moves one component at a time; threads: 2 T <=
     // RF_TWO_WG_MAXT = 1024, i.e. 4 waves per SIMD and 128 VGPRs): the exchanges are barrier-separated phases in which the whole
@@ -534,15 +539,24 @@ struct RfShape {
     // the second workgroup means 5 waves per SIMD and 96 VGPRs: the plain transform fits without spills but gains nothing
     // (0.343 -> 0.350 ms, it is HBM-bound at 4.7 TB/s), the transposing store spills (0.43 -> 0.65 ms) and the fused pad kernel
     // loses its LDS image row (1.90 -> 2.34 ms) -- RF_TWO_WG_MAXT stays at 1024.
-    static constexpr bool TWO_WG_SPLIT = ALLOW_DUAL && ALLOW_SPLIT && E == 16 && 2 * N * int(sizeof(double)) <= 160 * 1024 && 2 * T <= RF_TWO_WG_MAXT;
+    static constexpr int NLX = N + ((LEAD_ == 1 && N >= 4096 && E == 16) ? N / 16 : 0);  // (component length before XPAD is known)
+    static constexpr bool TWO_WG_SPLIT = ALLOW_DUAL && ALLOW_SPLIT && E == 16 && 2 * NLX * int(sizeof(double)) <= 160 * 1024 && 2 * T <= RF_TWO_WG_MAXT;
 #ifdef RF_NO_DUAL
     static constexpr bool DUAL = false;
 #else
-    static constexpr bool DUAL = ALLOW_DUAL && E == 16 && N * 16 <= 160 * 1024 && !(TWO_WG_SPLIT && 2 * N * 16 > 160 * 1024);
+    static constexpr bool DUAL = ALLOW_DUAL && E == 16 && NLX * 16 <= 160 * 1024 && !(TWO_WG_SPLIT && 2 * NLX * 16 > 160 * 1024);
 #endif
     // unused doubles behind every 16 LEAD positions of the exchange after the first radix-16 pass (see rf_transpose)
     static constexpr int XPAD = (!DUAL && LEAD_ > 1 && K_ >= 8 && E == 16) ? RF_XPAD : 0;
-    static constexpr int LDS_BYTES = ((DUAL ? 2 : 1) * N + XPAD * (N / (16 * LEAD_))) * int(sizeof(double));
+    // padding (doubles per block of R Ns positions) of the exchange behind a radix-R pass at sub-length Ns
+    static constexpr int xpad(int R, int Ns)
+    {
+        if (LEAD_ > 1) return (R == 16 && Ns == LEAD_) ? XPAD : 0;
+        if (SWZ) return 0;
+        return (R == 16 && Ns == 1) ? 1 : ((R == 16 && Ns == 16) ? 16 : 0);
+    }
+    static constexpr int NL = N + (LEAD_ > 1 ? XPAD * (N / (16 * LEAD_)) : (SWZ ? 0 : N / 16));  // doubles per LDS component
+    static constexpr int LDS_BYTES = (DUAL ? 2 : 1) * NL * int(sizeof(double));
     // (the fused kernels, ALLOW_DUAL = false, add their image row to the LDS: one workgroup per CU)
     static constexpr int WG_PER_CU = (ALLOW_DUAL && 2 * LDS_BYTES <= 160 * 1024 && 2 * T <= RF_TWO_WG_MAXT) ? 2 : 1;
     static constexpr int WAVES_PER_SIMD = (WG_PER_CU * ((T + 63) / 64) + 3) / 4;  // register budget = 512 / this
@@ -561,6 +575,7 @@ struct RfShape2 {
     static constexpr bool DUAL = S1::DUAL;
     static constexpr bool SWZ = S1::SWZ;
     static constexpr int XPAD = S1::XPAD;
+    static constexpr int NL = S1::NL;
     static constexpr int LDS_BYTES = S1::LDS_BYTES;
     static constexpr int WG_PER_CU = 1;
     static constexpr int WAVES_PER_SIMD = ((T + 63) / 64 + 3) / 4;
@@ -584,7 +599,7 @@ __device__ __forceinline__ void rf_passes(double (&re)[S::E], double (&im)[S::E]
         constexpr int R2 = rf_radix(S::K, P + 1);
         double2 w2[S::E / R2];
         rf_load_twiddles<R2, S::E>(w2, t, S::T, S::N, NS * R, tw);
-        rf_transpose<R, S::E, S::DUAL, S::SWZ, S::T, S::N, NS, (R == 16 && NS == S::LEAD) ? S::XPAD : 0>(re, im, t, lds);
+        rf_transpose<R, S::E, S::DUAL, S::SWZ, S::T, S::N, NS, S::xpad(R, NS), S::NL>(re, im, t, lds);
         rf_passes<S, P + 1, NS * R>(re, im, t, tw, lds, w2);
     }
 }
@@ -633,7 +648,7 @@ __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, L
     double2 w0[S::E / R0] = {};
     if constexpr (S::LEAD > 1) {
         rf_load_twiddles<R0, S::E>(w0, t, S::T, S::N, S::LEAD, tw);
-        rf_first_odd<S::LEAD, S::E, S::DUAL, S::SWZ, S::T, S::N>(re, im, t, ld, inverse, lds);
+        rf_first_odd<S::LEAD, S::E, S::DUAL, S::SWZ, S::T, S::N, S::NL>(re, im, t, ld, inverse, lds);
     } else {
 #pragma unroll
         for (int e = 0; e < S::E; ++e) {
