@@ -147,27 +147,44 @@ def as_c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
-_pinned_pool = {}  # nbytes -> [address, ...]: page-locked buffers whose arrays were garbage-collected
-_PINNED_POOL_BYTES = int(os.environ.get("PFBHIP_PINNED_POOL_MB", "4096")) << 20
+# Page-locked result buffers whose arrays were garbage-collected wait here for the next result of the same size.  The pool is
+# bounded (PFBHIP_PINNED_POOL_MB, default 2048) and evicts its OLDEST buffers first: a long-running process that returns
+# arrays of many different sizes must not pile up locked memory -- the HIP runtime aborts the process when its own pinned
+# allocations fail.
+_pinned_pool = []  # [(nbytes, address), ...] oldest first
+_PINNED_POOL_BYTES = int(os.environ.get("PFBHIP_PINNED_POOL_MB", "2048")) << 20
 _pinned_pooled = [0]
 _PINNED_MIN_BYTES = 1 << 20
 
 
+def _pinned_free(addr):
+    try:
+        lib().pfbhip_host_free(vp(addr))
+    except Exception:
+        pass
+
+
+def _pinned_trim(limit):
+    while _pinned_pool and _pinned_pooled[0] > limit:
+        nbytes, addr = _pinned_pool.pop(0)
+        _pinned_pooled[0] -= nbytes
+        _pinned_free(addr)
+
+
 def _pinned_release(addr, nbytes):
-    if _pinned_pooled[0] + nbytes <= _PINNED_POOL_BYTES:
-        _pinned_pool.setdefault(nbytes, []).append(addr)
-        _pinned_pooled[0] += nbytes
-    else:
-        try:
-            lib().pfbhip_host_free(vp(addr))
-        except Exception:
-            pass
+    if nbytes > _PINNED_POOL_BYTES:
+        _pinned_free(addr)
+        return
+    _pinned_pool.append((nbytes, addr))
+    _pinned_pooled[0] += nbytes
+    _pinned_trim(_PINNED_POOL_BYTES)
 
 
 def result_empty(shape, dtype):
     """``np.empty(shape, dtype)`` for an array this package RETURNS (dirty image, visibilities), backed by page-locked host
     memory so that the device-to-host copy runs at the PCIe rate.  The buffer goes back to a small pool when the array (and
-    every view of it) has been garbage-collected; small arrays are ordinary numpy allocations."""
+    every view of it) has been garbage-collected; small arrays are ordinary numpy allocations, and so is any array whose
+    page-locked allocation fails (after the pool has been emptied)."""
     import weakref
 
     dtype = np.dtype(dtype)
@@ -175,13 +192,18 @@ def result_empty(shape, dtype):
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if nbytes < _PINNED_MIN_BYTES or os.environ.get("PFBHIP_PINNED_RESULTS", "1") == "0":
         return np.empty(shape, dtype=dtype)
-    free = _pinned_pool.get(nbytes)
-    if free:
-        addr = free.pop()
-        _pinned_pooled[0] -= nbytes
-    else:
+    addr = None
+    for i in range(len(_pinned_pool) - 1, -1, -1):  # newest first
+        if _pinned_pool[i][0] == nbytes:
+            addr = _pinned_pool.pop(i)[1]
+            _pinned_pooled[0] -= nbytes
+            break
+    if addr is None:
         p = vp()
-        check(lib().pfbhip_host_alloc(ct.byref(p), ct.c_size_t(nbytes)))
+        if lib().pfbhip_host_alloc(ct.byref(p), ct.c_size_t(nbytes)) != 0:
+            _pinned_trim(0)
+            if lib().pfbhip_host_alloc(ct.byref(p), ct.c_size_t(nbytes)) != 0:
+                return np.empty(shape, dtype=dtype)
         addr = p.value
     buf = (ct.c_char * nbytes).from_address(addr)
     weakref.finalize(buf, _pinned_release, addr, nbytes)  # runs when the last array / view over `buf` is gone

@@ -43,9 +43,12 @@ inline std::string strprintf(const char *fmt, ...)
     } while (0)
 
 // Runs body(), converting C++ exceptions into C status codes.
+void debug_install_signals();  // PFBHIP_BACKTRACE=1: native backtrace on SIGABRT / SIGSEGV (runtime.cpp)
+
 template <class F>
 int guarded(F &&body) noexcept
 {
+    debug_install_signals();
     try {
         body();
         return PFBHIP_OK;

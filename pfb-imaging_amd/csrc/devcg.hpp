@@ -72,11 +72,57 @@ static __global__ void __launch_bounds__(CG_THREADS) k_cg_init(int64_t n, const 
     block_reduce_store<2>(v, partials);
 }
 
+// The CG scalars live on the device (scal: [0] alpha, [1] beta, [2] r.r of the current residual, [3] p.p, [4] x.x): the
+// loop enqueues a whole iteration -- operator, dot, alpha, update, beta, new direction -- without waiting for the host,
+// and reads the three numbers of the stopping rule back once per iteration, behind the last kernel.  (Two host round
+// trips per iteration before; on a busy host each one cost the GPU milliseconds of idle time.)
+// One block: sum of the CG_BLOCKS partials of ns quantities, in a fixed order.
+template <int NS>
+__device__ __forceinline__ void cg_sum_partials(const double *partials, double (&out)[NS])
+{
+    __shared__ double sm[NS][CG_THREADS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double t = 0.0;
+        for (int i = threadIdx.x; i < CG_BLOCKS; i += CG_THREADS) t += partials[size_t(s) * CG_BLOCKS + i];
+        sm[s][threadIdx.x] = t;
+    }
+    __syncthreads();
+    for (int o = CG_THREADS / 2; o > 0; o >>= 1) {
+        if (int(threadIdx.x) < o)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sm[s][threadIdx.x] += sm[s][threadIdx.x + o];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) out[s] = sm[s][0];
+}
+// alpha = r.r / p.Ap
+static __global__ void __launch_bounds__(CG_THREADS) k_cg_alpha(const double *partials, double *scal)
+{
+    double s[1];
+    cg_sum_partials<1>(partials, s);
+    if (threadIdx.x == 0) scal[0] = scal[2] / s[0];
+}
+// beta = r'.r' / r.r ; r.r <- r'.r' ; p.p and x.x for the stopping rule
+static __global__ void __launch_bounds__(CG_THREADS) k_cg_beta(const double *partials, double *scal)
+{
+    double s[3];
+    cg_sum_partials<3>(partials, s);
+    if (threadIdx.x == 0) {
+        scal[1] = s[0] / scal[2];
+        scal[2] = s[0];
+        scal[3] = s[1];
+        scal[4] = s[2];
+    }
+}
+
 // x += alpha p ; r += alpha ap ; partials [0] = r.r, [1] = p.p, [2] = x.x
-static __global__ void __launch_bounds__(CG_THREADS) k_cg_update(int64_t n, double alpha, const double *p,
+static __global__ void __launch_bounds__(CG_THREADS) k_cg_update(int64_t n, const double *scal, const double *p,
                                                                   const double *ap, double *x, double *r,
                                                                   double *partials)
 {
+    const double alpha = scal[0];
     double v[3] = {0.0, 0.0, 0.0};
     for (int64_t i = blockIdx.x * int64_t(CG_THREADS) + threadIdx.x; i < n; i += int64_t(CG_BLOCKS) * CG_THREADS) {
         double pi = p[i];
@@ -91,8 +137,9 @@ static __global__ void __launch_bounds__(CG_THREADS) k_cg_update(int64_t n, doub
     block_reduce_store<3>(v, partials);
 }
 
-static __global__ void __launch_bounds__(CG_THREADS) k_cg_newp(int64_t n, double beta, const double *r, double *p)
+static __global__ void __launch_bounds__(CG_THREADS) k_cg_newp(int64_t n, const double *scal, const double *r, double *p)
 {
+    const double beta = scal[1];
     for (int64_t i = blockIdx.x * int64_t(CG_THREADS) + threadIdx.x; i < n; i += int64_t(CG_BLOCKS) * CG_THREADS)
         p[i] = beta * p[i] - r[i];
 }
@@ -100,12 +147,20 @@ static __global__ void __launch_bounds__(CG_THREADS) k_cg_newp(int64_t n, double
 struct DevCG {
     int64_t n;
     hipStream_t stream;
-    DevBuf<double> r, p, ap, partials;
+    DevBuf<double> r, p, ap, partials, scal;
     std::vector<double> host;
+    double *hscal = nullptr;  // pinned: the per-iteration read-back
     DevCG(int64_t n_, hipStream_t st) : n(n_), stream(st), r(size_t(n_)), p(size_t(n_)), ap(size_t(n_)),
-                                         partials(size_t(3) * CG_BLOCKS), host(size_t(3) * CG_BLOCKS)
+                                         partials(size_t(3) * CG_BLOCKS), scal(8), host(size_t(3) * CG_BLOCKS)
     {
+        PFB_HIP(hipHostMalloc(reinterpret_cast<void **>(&hscal), 8 * sizeof(double), hipHostMallocDefault));
     }
+    ~DevCG()
+    {
+        if (hscal) (void)hipHostFree(hscal);
+    }
+    DevCG(const DevCG &) = delete;
+    DevCG &operator=(const DevCG &) = delete;
     void fetch(int ns, double *out)
     {
         PFB_HIP(hipMemcpyAsync(host.data(), partials.p, size_t(ns) * CG_BLOCKS * sizeof(double), hipMemcpyDeviceToHost,
@@ -132,25 +187,26 @@ struct DevCG {
         if (s[1] == 0.0) {
             status = 3;  // initial residual is zero
         } else {
+            hscal[2] = rnorm;
+            PFB_HIP(hipMemcpyAsync(scal.p + 2, hscal + 2, sizeof(double), hipMemcpyHostToDevice, stream));
             while ((eps > tol || k < minit) && k < maxit && stall < 5) {
                 aop(p.p, ap.p);
                 hipLaunchKernelGGL(k_cg_dot2, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, stream, n, p.p, ap.p, p.p, p.p,
                                    partials.p);
-                PFB_HIP(hipGetLastError());
-                fetch(1, s);
-                double alpha = rnorm / s[0];
-                hipLaunchKernelGGL(k_cg_update, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, stream, n, alpha, p.p, ap.p, x_dev,
+                hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(CG_THREADS), 0, stream, partials.p, scal.p);
+                hipLaunchKernelGGL(k_cg_update, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, stream, n, scal.p, p.p, ap.p, x_dev,
                                    r.p, partials.p);
+                hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(CG_THREADS), 0, stream, partials.p, scal.p);
+                // (the new direction is formed before the host has looked at the stopping rule: harmless if the loop ends)
+                hipLaunchKernelGGL(k_cg_newp, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, stream, n, scal.p, r.p, p.p);
                 PFB_HIP(hipGetLastError());
-                fetch(3, s);
-                double rnorm_next = s[0];
-                double beta = rnorm_next / rnorm;
-                hipLaunchKernelGGL(k_cg_newp, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, stream, n, beta, r.p, p.p);
-                PFB_HIP(hipGetLastError());
-                rnorm = rnorm_next;
+                PFB_HIP(hipMemcpyAsync(hscal, scal.p, 5 * sizeof(double), hipMemcpyDeviceToHost, stream));
+                PFB_HIP(hipStreamSynchronize(stream));
+                const double alpha = hscal[0];
+                rnorm = hscal[2];
                 ++k;
                 double epsp = eps;
-                eps = std::sqrt(alpha * alpha * s[1] / std::max(s[2], 1e-12));
+                eps = std::sqrt(alpha * alpha * hscal[3] / std::max(hscal[4], 1e-12));
                 if (std::fabs(epsp - eps) < 1e-3 * tol) ++stall;
             }
             status = k >= maxit ? 1 : (stall >= 5 ? 2 : 0);

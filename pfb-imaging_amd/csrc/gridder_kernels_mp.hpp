@@ -474,7 +474,10 @@ struct VisRec {
     int key;        // (lu << 8) | lv: the first-tap cell itself (gather; SKIP test of k_grid_rec)
 };
 static_assert(sizeof(VisRec) == 32, "VisRec layout");
-constexpr int REC_PAD = 8;  // entries allocated past the last record / value (the loop requests up to 3 ahead)
+// entries allocated past the last record / value: the loop requests up to 3 ahead, and the L2 warm-up (`touch`) one entry per
+// lane up to 63 + 63 past the visibility it is at.  (With 8 the warm-up of the LAST work item read ~7 KB past the arrays: harmless
+// inside an allocation's slack, a memory fault when a small plan's arrays ended at a page boundary.)
+constexpr int REC_PAD = 136;
 
 template <int W, int KP>
 __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, const VisRec *__restrict__ rec,

@@ -14,7 +14,32 @@
 
 #include "common.hpp"
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
+namespace {
+// PFBHIP_BACKTRACE=1: native backtrace on SIGABRT / SIGSEGV (the Python fault handler only shows the Python frames)
+void pfbhip_fatal_signal(int sig)
+{
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "[pfbhip] fatal signal, native backtrace:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+}  // namespace
+
 namespace pfbhip {
+void debug_install_signals()
+{
+    static const bool on = [] { const char *e = std::getenv("PFBHIP_BACKTRACE"); return e != nullptr && e[0] == '1'; }();
+    if (!on) return;
+    signal(SIGABRT, pfbhip_fatal_signal);  // (re-armed at every API call: other libraries install handlers of their own)
+    signal(SIGSEGV, pfbhip_fatal_signal);
+}
 
 static thread_local std::string t_last_error;
 
