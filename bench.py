@@ -429,7 +429,7 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
                 "bound": "hbm", "kernel": names.get(dom, dom), "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 # not measured in this run: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) are separate runs, see profiles/
-                "traffic": None, "traffic_profile": "profiles/r02e_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
+                "traffic": None, "traffic_profile": "profiles/r02f_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
                 "alg_bytes_per_launch": per_launch[dom], "avg_launch_ms": avg_ms, "launches": dom_calls,
                 "actual_bytes_per_apply": actual,
                 "actual_frac": actual / apply_s / 1e9 / HBM_PEAK_GBS,
