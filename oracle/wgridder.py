@@ -170,8 +170,8 @@ def nm1_image(nx, ny, px, py, lshift, mshift):
 
 def nm1_range(nx, ny, px, py, lshift, mshift):
     """min/max of n-1 over the image (corners, plus axis crossings)."""
-    x0 = lshift - 0.5 * nx * px
-    y0 = mshift - 0.5 * ny * py
+    x0 = lshift - (nx // 2) * px  # pixel i sits at (i - n // 2) * pixsize (odd sizes: symmetric lattice)
+    y0 = mshift - (ny // 2) * py
     xs = [x0, x0 + (nx - 1) * px]
     ys = [y0, y0 + (ny - 1) * py]
     if xs[0] * xs[1] < 0:

@@ -1144,6 +1144,9 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
             }
         }
     }
+    PFB_REQUIRE(best != nullptr || !(wgrid && prm.force_wmode == 2),  // (C-ABI encoding: 0 = plan decides, wmode + 1 otherwise)
+                "force_wmode=1: the polynomial w-plane scheme needs more than %d planes for this field of view and w range "
+                "(epsilon=%g); leave the scheme to the plan", MAX_POLY_PLANES, prm.epsilon);
     PFB_REQUIRE(best != nullptr, "no ES kernel reaches epsilon=%g with sigma in [%g, %g] (double precision floor ~1e-12)",
                 prm.epsilon, prm.sigma_min, prm.sigma_max);
     auto &info = g->info;
@@ -1181,7 +1184,9 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
 static void nm1_range(const pfbhip_gridder_params &p, double lshift, double mshift, double *lo, double *hi)
 {
     // corners of the pixel-centre lattice plus axis crossings (cf. oracle/wgridder.py: nm1_range)
-    double x0 = lshift - 0.5 * double(p.nx) * p.pixsize_x, y0 = mshift - 0.5 * double(p.ny) * p.pixsize_y;
+    // pixel i sits at (i - n / 2) * pixsize with INTEGER n / 2: for odd sizes the lattice runs from -(n-1)/2 to +(n-1)/2 (0.5 * n
+    // put it half a pixel low: the last pixel's |n - 1| then exceeded the bound the plane spacing and the psi_w fit are built on)
+    double x0 = lshift - double(p.nx / 2) * p.pixsize_x, y0 = mshift - double(p.ny / 2) * p.pixsize_y;
     std::vector<double> xs{x0, x0 + double(p.nx - 1) * p.pixsize_x}, ys{y0, y0 + double(p.ny - 1) * p.pixsize_y};
     if (xs[0] * xs[1] < 0) xs.push_back(0.0);
     if (ys[0] * ys[1] < 0) ys.push_back(0.0);
@@ -1634,12 +1639,11 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     const int64_t nblk = ceil_div(info.nu, TP);
     std::vector<uint8_t> occ(size_t(nblk), 0);
     static_assert(TP == TILE, "row-block occupancy assumes transpose tile == uv tile");
+    // (every block a footprint row can fall in: with a short last block -- nu % 32 < W - 1 -- the footprints of the tile
+    // before it run THROUGH that block and wrap into block 0; marking only the first and the last row's block left it out)
     for (const WorkItem &wi : work) {
-        int64_t tu = wi.tile / uint32_t(m.ntv);
-        occ[size_t(tu)] = 1;
-        int64_t last_row = (tu * TILE + TILE + info.W - 2) % info.nu;  // last cell row the tile's footprint can touch
-        occ[size_t(last_row / TP)] = 1;
-        if (tu * TILE + TILE + info.W - 2 >= info.nu) occ[0] = 1;
+        const int64_t tu = wi.tile / uint32_t(m.ntv);
+        for (int64_t r = tu * TILE; r <= tu * TILE + TILE + info.W - 2; ++r) occ[size_t((r % info.nu) / TP)] = 1;
     }
     {   // column runs per tile row (default: the whole row)
         const int64_t ntu_t = ceil_div(info.nu, TILE), ntv_t = m.ntv;
@@ -1648,9 +1652,9 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             std::vector<uint8_t> touched(size_t(ntu_t * ntv_t), 0);
             for (const WorkItem &wi : work) {
                 const int64_t tu = wi.tile / uint32_t(m.ntv), tv = wi.tile % uint32_t(m.ntv);
-                for (int du = 0; du < 2; ++du)
-                    for (int dv = 0; dv < 2; ++dv)
-                        touched[size_t(((tu + du) % ntu_t) * ntv_t + (tv + dv) % ntv_t)] = 1;
+                for (int64_t r = tu * TILE; r <= tu * TILE + TILE + info.W - 2; ++r)
+                    for (int64_t q = tv * TILE; q <= tv * TILE + TILE + info.W - 2; ++q)
+                        touched[size_t(((r % info.nu) / TILE) * ntv_t + (q % info.nv) / TILE)] = 1;
             }
             for (int64_t tu = 0; tu < ntu_t; ++tu) {
                 std::vector<std::pair<int, int>> rr;
@@ -1686,9 +1690,9 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         std::vector<uint8_t> touched(size_t(ntu_t * ntv_t), 0);
         for (const WorkItem &wi : work) {
             const int64_t tu = wi.tile / uint32_t(m.ntv), tv = wi.tile % uint32_t(m.ntv);
-            for (int du = 0; du < 2; ++du)
-                for (int dv = 0; dv < 2; ++dv)  // W - 1 < TILE: the footprints spill into the next tile only (wrapping)
-                    touched[size_t(((tu + du) % ntu_t) * ntv_t + (tv + dv) % ntv_t)] = 1;
+            for (int64_t r = tu * TILE; r <= tu * TILE + TILE + info.W - 2; ++r)  // every tile a footprint cell can fall in
+                for (int64_t q = tv * TILE; q <= tv * TILE + TILE + info.W - 2; ++q)
+                    touched[size_t(((r % info.nu) / TILE) * ntv_t + (q % info.nv) / TILE)] = 1;
         }
         std::vector<int4> rects;
         int64_t cells = 0, full = 0;
