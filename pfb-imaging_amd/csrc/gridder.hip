@@ -1057,7 +1057,7 @@ static int poly_planes_needed(double omega, double eps)
     return k;
 }
 
-static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax)
+static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax, double nmin)
 {
     const auto &prm = g->prm;
     size_t nrows = 0;
@@ -1065,7 +1065,9 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
     // admissible rows: worst-position (image-edge) 1-D error <= epsilon / ndim.  The L2 error over
     // the image is then ~4-5x smaller than requested; the stricter rule is what keeps max-norm
     // identities of the reference's tests (test_hessian_approx.py:188-231, |err|_inf <= epsilon) true.
-    const double eps1 = prm.epsilon / (prm.do_wgridding ? 3.0 : 2.0);
+    // divide_by_n weights a pixel's error with 1 / n: the budget shrinks by the smallest n of the image (a field reaching
+    // 45 degrees off axis: 0.7; found by the fuzz sweep: 1.17e-7 at epsilon = 1e-7 for a centre at (-0.2, 0.35))
+    const double eps1 = prm.epsilon / (prm.do_wgridding ? 3.0 : 2.0) * ((prm.do_wgridding && prm.divide_by_n) ? std::max(0.25, std::min(1.0, nmin)) : 1.0);
     const double nvis = double(g->nvis);
     const bool wgrid = prm.do_wgridding && tmax > 0.0;
     const double pi = 3.14159265358979323846;
@@ -1285,7 +1287,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     }
 
     lap("upload + w range");
-    choose_kernel(g, wlo, whi, tmax);
+    choose_kernel(g, wlo, whi, tmax, 1.0 + nm1min);
     PFB_REQUIRE(info.nplanes >= 1 && info.nplanes < 100000, "unreasonable number of w-planes (%lld)",
                 (long long)info.nplanes);
 
