@@ -34,6 +34,20 @@ for _i in range(int(os.environ.get("PFB_FUZZ_N", "24"))):
     ))
 
 
+# Regressions a longer sweep (PFB_FUZZ_SEED=7) found: uv-grids of 36 cells -- a last 32-row block of 4 rows that the footprints
+# of the block before it run through -- and odd image sizes with a shifted phase centre (the n - 1 range was half a pixel low).
+CASES += [
+    dict(nx=30, ny=27, nrow=841, nchan=3, eps=1e-3, widen=0.5, zscale=0.001, flips=(True, False, False), center=(0.01, -0.03),
+         do_w=False, divn=True, wmode=0, seed=2779),
+    dict(nx=64, ny=27, nrow=295, nchan=1, eps=1e-8, widen=2.0, zscale=0.5, flips=(False, True, False), center=(0.0, -0.03),
+         do_w=True, divn=False, wmode=0, seed=2146),
+    dict(nx=50, ny=27, nrow=72, nchan=3, eps=1e-5, widen=40.0, zscale=0.5, flips=(False, False, True), center=(0.0, 0.35),
+         do_w=True, divn=True, wmode=0, seed=5308),
+    dict(nx=64, ny=27, nrow=744, nchan=1, eps=1e-6, widen=40.0, zscale=0.5, flips=(True, False, True), center=(0.01, -0.03),
+         do_w=True, divn=True, wmode=0, seed=3165),
+]
+
+
 @pytest.mark.parametrize("k", range(len(CASES)))
 def test_fuzz_vs_dft(k):
     from pfb_imaging_amd.wgridder import Gridder
