@@ -528,6 +528,7 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
     for (int k = 0; k <= D; ++k) c[k] = (b < W && lane < 32) ? a.ktab[b * (D + 1) + k] : 0.0;
     // Warm the L2 with the records / values of 64 visibilities (one per lane) ahead of the walk, whose own requests --
     // two visibilities ahead -- then never wait for HBM.  The loaded words are consumed (an empty asm) at the next refresh.
+    static_assert(REC_PAD >= 63 + 63 + 3, "the warm-up reads one entry per lane up to 63 + 63 past the current visibility");
     auto touch = [&](uint32_t first) {
         const uint32_t jt = first + uint32_t(lane);  // (padded arrays: no clamp)
         const int t0 = *reinterpret_cast<const int *>(rbase + size_t(jt) * 32 + 16);
