@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--verbosity", type=int, default=0)
     ap.add_argument("--reduce-every", type=int, default=0,
                     help="C2: band reduce (RCCL sum-to-root) every this many applies; 0 = once per timed region")
+    ap.add_argument("--allow-no-rccl", action="store_true",
+                    help="N > 1 only: if the RCCL communicator cannot be created, measure the per-band work without the band "
+                         "exchange instead of failing (the line then says so; it is NOT a scaling measurement)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON of rank 0: native libraries (RCCL prints a version banner on fd 1 when
@@ -277,6 +280,10 @@ def main():
         rccl_error = "RCCL communicator failed on another rank"
     use_rccl = comm.world_size > 1 and rccl_error is None
     if rccl_error is not None:
+        if not args.allow_no_rccl:  # a multi-GPU line without its exchange step must not be mistaken for a scaling result
+            print(f"[bench rank {comm.rank}] RCCL unavailable: {rccl_error}\n--gpus {args.gpus} measures the band exchange over "
+                  "RCCL; pass --allow-no-rccl to time the per-band work alone", file=sys.stderr, flush=True)
+            raise SystemExit(3)
         print(f"[bench rank {comm.rank}] RCCL unavailable, band exchange skipped: {rccl_error}", file=sys.stderr, flush=True)
         if comm.transport == "rccl":  # ours came up but a peer's did not: stay off it
             comm.transport = "gloo"
@@ -408,6 +415,7 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
             "dtype": "f64",
             "data": "synthetic",
             "hessian_applies_per_s": world / apply_s,
+            "rccl_ranks": world if use_rccl else 0,
             "config": {
                 "workload": wl, "bands": world,
                 "w_scheme": "polynomial planes" if info["wmode"] == 1 else "ES-kernel planes",
@@ -529,7 +537,7 @@ def bench_c4(args, comm, use_rccl, rccl_error):
             "metric": "PSF-approximate Hessian applies/s inside the SARA primal-dual step (4 bands, 4096^2, Psi: self+db1+db2+db3, 3 levels)",
             "value": nband / per, "unit": "Hessian-applies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": per * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic", "rccl_ranks": world if use_rccl else 0,
             "config": {"workload": "C4: SARA backward step, 4 bands x 4096^2, PSF 8192^2, a step = one primal-dual iteration "
                                    "(Psi^H, l21 dual update, Psi, PSF Hessian, primal step, positivity)",
                        "bands": nband, "image": [n, n], "psf": [npsf, npsf], "bases": list(bases), "nlevels": nlevel,

@@ -350,11 +350,17 @@ int pfbhip_positivity_dev(double *x_dev, int64_t nband, int64_t n, int mode);
  * comm == NULL: all nband bands are on this device.  comm != NULL (one process per GPU, every rank calls
  * collectively): the arrays hold this rank's nband LOCAL bands; the band sum of the dual update, the
  * "any band <= 0" test of positivity mode 2 and the convergence norms are completed with all-reduces. */
+#define PFBHIP_PD_NSTAGES 5
 typedef struct pfbhip_pd_info {
     int32_t iters;
     int32_t status; /* 0 converged, 1 maxit reached */
     double eps;
     double loop_ms; /* wall time of the iteration loop alone (cubes resident in HBM: uploads / downloads excluded) */
+    /* device time (HIP events on the loop's stream) and number of bracketed launches per stage, summed over the iterations of
+     * runs with maxit <= 64 (zeros otherwise): 0 Psi^H analysis of all local bands, 1 l21 dual update, 2 Psi synthesis (one
+     * band per launch), 3 PSF-approximate Hessian (one partition apply per launch), 4 primal step + positivity + norms */
+    double stage_ms[PFBHIP_PD_NSTAGES];
+    int64_t stage_calls[PFBHIP_PD_NSTAGES];
 } pfbhip_pd_info;
 int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs /* [nband] */, int64_t nband, const int64_t *nparts, const int64_t *psf_slots,
                        const int64_t *beam_slots, const double *scale, const double *eta, const double *xtilde_host, double gamma,

@@ -46,8 +46,13 @@ class GridderInfo(ct.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+PD_NSTAGES = 5
+PD_STAGE_NAMES = ("psi_analysis", "dual_update", "psi_synthesis", "psf_hessian", "primal_step")
+
+
 class PDInfo(ct.Structure):
-    _fields_ = [("iters", i32), ("status", i32), ("eps", f64), ("loop_ms", f64)]
+    _fields_ = [("iters", i32), ("status", i32), ("eps", f64), ("loop_ms", f64), ("stage_ms", f64 * PD_NSTAGES),
+                ("stage_calls", i64 * PD_NSTAGES)]
 
 
 class PMInfo(ct.Structure):
@@ -155,9 +160,25 @@ _pinned_pool = []  # [(nbytes, address), ...] oldest first
 _PINNED_POOL_BYTES = int(os.environ.get("PFBHIP_PINNED_POOL_MB", "2048")) << 20
 _pinned_pooled = [0]
 _PINNED_MIN_BYTES = 1 << 20
+# LIVE page-locked bytes (pooled + held by arrays the caller still references) are bounded too: a caller that keeps the
+# DIRTY / PSF cubes of many bands would otherwise lock tens of GB.  Past the cap (PFBHIP_PINNED_MAX_MB; default a quarter of
+# the physical memory, at least 4 GiB) results are ordinary pageable numpy arrays -- slower device-to-host copies, nothing else.
+_pinned_live = [0]
 
 
-def _pinned_free(addr):
+def _pinned_cap():
+    env = os.environ.get("PFBHIP_PINNED_MAX_MB")
+    if env is not None:
+        return int(env) << 20
+    try:
+        phys = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    except (ValueError, OSError, AttributeError):
+        phys = 64 << 30
+    return max(phys // 4, 4 << 30)
+
+
+def _pinned_free(addr, nbytes=0):
+    _pinned_live[0] -= nbytes
     try:
         lib().pfbhip_host_free(vp(addr))
     except Exception:
@@ -168,12 +189,12 @@ def _pinned_trim(limit):
     while _pinned_pool and _pinned_pooled[0] > limit:
         nbytes, addr = _pinned_pool.pop(0)
         _pinned_pooled[0] -= nbytes
-        _pinned_free(addr)
+        _pinned_free(addr, nbytes)
 
 
 def _pinned_release(addr, nbytes):
     if nbytes > _PINNED_POOL_BYTES:
-        _pinned_free(addr)
+        _pinned_free(addr, nbytes)
         return
     _pinned_pool.append((nbytes, addr))
     _pinned_pooled[0] += nbytes
@@ -199,12 +220,17 @@ def result_empty(shape, dtype):
             _pinned_pooled[0] -= nbytes
             break
     if addr is None:
+        if _pinned_live[0] + nbytes > _pinned_cap():
+            _pinned_trim(0)  # idle buffers first
+            if _pinned_live[0] + nbytes > _pinned_cap():
+                return np.empty(shape, dtype=dtype)
         p = vp()
         if lib().pfbhip_host_alloc(ct.byref(p), ct.c_size_t(nbytes)) != 0:
             _pinned_trim(0)
             if lib().pfbhip_host_alloc(ct.byref(p), ct.c_size_t(nbytes)) != 0:
                 return np.empty(shape, dtype=dtype)
         addr = p.value
+        _pinned_live[0] += nbytes
     buf = (ct.c_char * nbytes).from_address(addr)
     weakref.finalize(buf, _pinned_release, addr, nbytes)  # runs when the last array / view over `buf` is gone
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
@@ -255,8 +281,10 @@ class DeviceArray:
             pass
 
 
-_ro_memo = {}  # (address, shape, dtype) -> (array kept alive, key): read-only inputs only
+_ro_memo = {}  # (address, shape, dtype) -> (array kept alive, key, sample): read-only inputs only
 _RO_MEMO_MAX = 32
+_RO_MEMO_BYTES = int(os.environ.get("PFBHIP_RO_MEMO_MB", "4096")) << 20  # bound on the bytes the memo keeps alive
+_ro_memo_bytes = [0]
 
 
 def _immutable(a):
@@ -270,13 +298,28 @@ def _immutable(a):
     return True
 
 
+def _sample(c):
+    """Cheap fingerprint of a C-contiguous array: <= 4096 evenly spaced 8-byte words plus the tail.  It guards the memo of
+    content_key against memory that changes underneath a read-only view (an owner that flips ``writeable`` on, edits and flips
+    it off again; a read-only view over shared memory or a writable mmap): not a proof of equality -- the full hash is --
+    but an edit would have to miss every sampled word to go unnoticed."""
+    b = c.reshape(-1).view(np.uint8)
+    nw = b.size // 8
+    if nw == 0:
+        return b.tobytes()
+    w = b[: nw * 8].view(np.uint64)
+    step = max(nw // 4096, 1)
+    return w[::step].tobytes() + b[nw * 8:].tobytes() + w[-1:].tobytes()
+
+
 def content_key(a):
     """(shape, dtype, 64-bit hash of EVERY byte) of a host array, or None: the plan-cache key component for an input.
 
     The stateless ducc0-style calls may reuse a cached plan only for byte-identical inputs; a sampled fingerprint keyed on
     the address misses in-place edits and reallocations at the same address.  The hash (pfbhip_hash64, multi-threaded)
-    costs a pass over the array per call; arrays that cannot change -- read-only views all the way down -- are hashed once
-    and remembered by address for as long as the memo keeps them alive."""
+    costs a pass over the array per call; arrays that cannot change through numpy -- read-only views all the way down -- are
+    hashed once and remembered by address for as long as the memo keeps them alive (bounded by entries and by bytes); a hit
+    is confirmed against a sampled fingerprint of the current contents (see _sample)."""
     if a is None:
         return None
     a = np.asarray(a)
@@ -285,13 +328,18 @@ def content_key(a):
         mk = (a.ctypes.data, a.shape, a.dtype.str)
         hit = _ro_memo.get(mk)
         if hit is not None:
-            return hit[1]
+            if hit[2] == _sample(a):
+                return hit[1]
+            _ro_memo_bytes[0] -= hit[0].nbytes
+            del _ro_memo[mk]
     c = np.ascontiguousarray(a)
     key = (c.shape, c.dtype.str, int(lib().pfbhip_hash64(c.ctypes.data_as(ct.c_void_p), ct.c_size_t(c.nbytes))))
-    if ro:
-        while len(_ro_memo) >= _RO_MEMO_MAX:
-            _ro_memo.pop(next(iter(_ro_memo)))
-        _ro_memo[mk] = (a, key)  # holding `a` keeps its buffer from being freed and the address from being reused
+    if ro and a.nbytes <= _RO_MEMO_BYTES:
+        while _ro_memo and (len(_ro_memo) >= _RO_MEMO_MAX or _ro_memo_bytes[0] + a.nbytes > _RO_MEMO_BYTES):
+            old = _ro_memo.pop(next(iter(_ro_memo)))
+            _ro_memo_bytes[0] -= old[0].nbytes
+        _ro_memo[mk] = (a, key, _sample(a))  # holding `a` keeps its buffer from being freed and the address from being reused
+        _ro_memo_bytes[0] += a.nbytes
     return key
 
 

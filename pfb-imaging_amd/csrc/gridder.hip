@@ -764,15 +764,29 @@ struct pfbhip_gridder {
         hipLaunchKernelGGL((k_degrid_mp<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds_bytes_mp<W>(), stream, ga,
                            grid_cur, sacc, want_pval ? d_swgt.p : nullptr, want_pval ? d_pval.p : nullptr);
     }
-    template <int W, int KP>
-    void launch_degrid_rw_wk(const GroupArgs &ga, double2 *sacc)
+    int rw_depth = 0;  // PFBHIP_RW_DEPTH (experiment): explicit LDS prefetch distance of the row-walk gather, (W, KP) = (16, 3) only
+    template <int W, int KP, int PD>
+    void launch_degrid_rw_d(const GroupArgs &ga, double2 *sacc)
     {
-        allow_dynamic_lds(reinterpret_cast<const void *>(&k_degrid_rw<W, KP>), 160 * 1024);
+        allow_dynamic_lds(reinterpret_cast<const void *>(&k_degrid_rw<W, KP, PD>), 160 * 1024);
         const size_t lds = size_t(KP) * RW_LS * RW_LS * sizeof(double2);
         GroupArgs gs = ga;
         if (stamp_mode == 2 && d_stamps.p != nullptr) gs.dbg = d_stamps.p;
-        hipLaunchKernelGGL((k_degrid_rw<W, KP>), dim3(ga.a.nwork), dim3(MP_THREADS), lds, stream, gs, d_rec.p, d_kw.p, grid_cur,
+        hipLaunchKernelGGL((k_degrid_rw<W, KP, PD>), dim3(ga.a.nwork), dim3(MP_THREADS), lds, stream, gs, d_rec.p, d_kw.p, grid_cur,
                            sacc, want_pval ? d_swgt.p : nullptr, want_pval ? d_pval.p : nullptr);
+    }
+    template <int W, int KP>
+    void launch_degrid_rw_wk(const GroupArgs &ga, double2 *sacc)
+    {
+        if constexpr (W == 16 && KP == 3) {
+            switch (rw_depth) {
+                case 1: launch_degrid_rw_d<W, KP, 1>(ga, sacc); return;
+                case 2: launch_degrid_rw_d<W, KP, 2>(ga, sacc); return;
+                case 3: launch_degrid_rw_d<W, KP, 3>(ga, sacc); return;
+                default: break;
+            }
+        }
+        launch_degrid_rw_d<W, KP, 0>(ga, sacc);
     }
     template <int W>
     void launch_degrid_mp_w(int plane0, int kp, double2 *sacc)
@@ -952,7 +966,7 @@ struct pfbhip_gridder {
     // x -> sacc, folding the x * corr * beam step into the fused pad kernel where possible
     void prepare_and_degrid(const double *x, const double *beam, double2 *sacc)
     {
-        if (fused && info.nactive != 0 && info.nwork != 0) {
+        if (fused && info.nactive != 0 && info.nwork != 0 && fused_pad_takes_prep(rowfft_u, fgeom)) {
             FusedPrep p;
             p.x = x;
             p.corr = d_corr.p;
@@ -1438,6 +1452,8 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     {
         const char *genv = std::getenv("PFBHIP_GATHER");
         g->gather_rw = rec_mode && !(genv != nullptr && std::string(genv) == "walk");
+        const char *denv = std::getenv("PFBHIP_RW_DEPTH");
+        g->rw_depth = denv != nullptr ? std::max(0, std::min(3, std::atoi(denv))) : 0;
     }
     if (rec_mode) {
         g->d_rec.alloc(size_t(info.nactive) + REC_PAD);

@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
 //    gather's epilogue in a Hessian apply, by k_plane_values otherwise);
 //  * key / offsets / values are wave-uniform and come in through SCALAR loads (SGPR operands of the FMAs: no
 //    v_readlane), the kernel argument through one vector load (lanes 0..15 read zu, lanes 16..31 zv); records are
-//    addressed with running 32-bit byte offsets (arrays padded by REC_PAD entries: no clamping);
+//    addressed with running 32-bit byte offsets from the wave's own first record (arrays padded by REC_PAD entries: no clamping);
 //  * three register sets and three scratch lines used round robin by a loop unrolled three times (static indices):
 //    a visibility's data are requested two iterations before use;
 //  * the scalar requests are issued BEHIND the wait for the scratch reads (scalar loads return out of order: a wait on
@@ -603,12 +603,17 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
     int cur = -1;
     int4 kq[3];
     double2 pq[3][KP];
-    uint32_t roff = j0 * 32u + 16u, poff = j0 * pbytes;  // byte offsets of the next scalar requests (visibility s + 2 ...)
+    // Byte offsets of the next scalar requests (visibility s + 2 ...), RELATIVE to this wave's first record / value: a wave
+    // walks at most CHUNK visibilities, so the 32-bit offsets stay below 2^19 whatever the plan's size.  (Absolute offsets
+    // j0 * 32 and j0 * pbytes wrap at 1.3e8 / 6.7e7 active visibilities and silently address other visibilities' data.)
+    const char *const rwave = rbase + size_t(j0) * 32;
+    const char *const pwave = pbase + size_t(j0) * size_t(pbytes);
+    uint32_t roff = 16u, poff = 0u;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        kq[u] = *reinterpret_cast<const int4 *>(rbase + roff);
+        kq[u] = *reinterpret_cast<const int4 *>(rwave + roff);
 #pragma unroll
-        for (int p = 0; p < KP; ++p) pq[u][p] = *reinterpret_cast<const double2 *>(pbase + poff + p * 16);
+        for (int p = 0; p < KP; ++p) pq[u][p] = *reinterpret_cast<const double2 *>(pwave + poff + p * 16);
         roff += 32u;
         poff += pbytes;
     }
@@ -656,9 +661,9 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
             for (int k = 0; k < NR; ++k) asm volatile("" : "+v"(kuv[k])::"memory");
             double kvc_ = kvc;
             asm volatile("" : "+v"(kvc_)::"memory");
-            kq[ld] = *reinterpret_cast<const int4 *>(rbase + roff);
+            kq[ld] = *reinterpret_cast<const int4 *>(rwave + roff);
 #pragma unroll
-            for (int p = 0; p < KP; ++p) pq[ld][p] = *reinterpret_cast<const double2 *>(pbase + poff + p * 16);
+            for (int p = 0; p < KP; ++p) pq[ld][p] = *reinterpret_cast<const double2 *>(pwave + poff + p * 16);
             roff += 32u;
             poff += pbytes;
             __builtin_amdgcn_sched_barrier(0);
@@ -735,17 +740,56 @@ __device__ __forceinline__ void fmac_row_bcast(double &acc, double ku, double ce
 
 // planes 0, 1 are addressed from base, planes 2, 3 from base2 = base + 2 tiles: every offset is a 16-bit immediate
 template <int KP, int I>
-__device__ __forceinline__ void rw_steps(const char *base, const char *base2, double ku, double (&sr)[KP], double (&si)[KP])
+__device__ __forceinline__ void rw_load_row(const char *base, const char *base2, double2 (&cell)[KP])
+{
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const char *bp = k < 2 ? base : base2;
+        cell[k] = *reinterpret_cast<const double2 *>(bp + (size_t(k & 1) * RW_LS * RW_LS + size_t(I) * RW_LS) * 16);
+    }
+}
+
+// Prefetch distance of the row walk, in footprint rows (experiment, round 3).  Left to itself the compiler keeps TWO
+// ds_read_b128 in flight (issue 2, wait for the first, 2 FMAs ...).  With D > 0 the reads of row I + D are issued before the
+// FMAs of row I, D * KP reads in flight (at most 15: lgkmcnt is a 4-bit counter), in D + 1 static register sets.
+// MEASURED on C2 (W = 16, KP = 3): D = 3 is 26 % SLOWER (2.24 vs 1.77 ms) -- see DESIGN.md section 5.2; D = 0 (the compiler's
+// schedule) stays the default, PFBHIP_RW_DEPTH selects 1..3 for the (16, 3) instantiation.
+template <int KP, int D, int I>
+__device__ __forceinline__ void rw_steps(const char *base, const char *base2, double ku, double (&sr)[KP], double (&si)[KP],
+                                         double2 (&buf)[D + 1][KP])
 {
     if constexpr (I < 16) {
+        if constexpr (I + D < 16) rw_load_row<KP, I + D>(base, base2, buf[(I + D) % (D + 1)]);
+        __builtin_amdgcn_sched_barrier(0);  // keeps the requests above in front of the FMAs below
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            const char *bp = k < 2 ? base : base2;
-            const double2 cell = *reinterpret_cast<const double2 *>(bp + (size_t(k & 1) * RW_LS * RW_LS + size_t(I) * RW_LS) * 16);
-            fmac_row_bcast<I>(sr[k], ku, cell.x);  // (v_mul_f64 has no DPP form: the accumulators start from zero)
-            fmac_row_bcast<I>(si[k], ku, cell.y);
+            fmac_row_bcast<I>(sr[k], ku, buf[I % (D + 1)][k].x);  // (v_mul_f64 has no DPP form: the accumulators start from zero)
+            fmac_row_bcast<I>(si[k], ku, buf[I % (D + 1)][k].y);
         }
-        rw_steps<KP, I + 1>(base, base2, ku, sr, si);
+        __builtin_amdgcn_sched_barrier(0);
+        rw_steps<KP, D, I + 1>(base, base2, ku, sr, si, buf);
+    }
+}
+template <int KP, int I>
+__device__ __forceinline__ void rw_steps0(const char *base, const char *base2, double ku, double (&sr)[KP], double (&si)[KP])
+{
+    if constexpr (I < 16) {
+        double2 cell[KP];
+        rw_load_row<KP, I>(base, base2, cell);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            fmac_row_bcast<I>(sr[k], ku, cell[k].x);
+            fmac_row_bcast<I>(si[k], ku, cell[k].y);
+        }
+        rw_steps0<KP, I + 1>(base, base2, ku, sr, si);
+    }
+}
+template <int KP, int D, int I>
+__device__ __forceinline__ void rw_prologue(const char *base, const char *base2, double2 (&buf)[D + 1][KP])
+{
+    if constexpr (I < D) {
+        rw_load_row<KP, I>(base, base2, buf[I]);
+        rw_prologue<KP, D, I + 1>(base, base2, buf);
     }
 }
 
@@ -764,7 +808,7 @@ __device__ __forceinline__ double half_row_sum(double v)
     return v;
 }
 
-template <int W, int KP>
+template <int W, int KP, int PD = 0>
 __global__ void __launch_bounds__(MP_THREADS) k_degrid_rw(GroupArgs ga, const VisRec *__restrict__ rec,
                                                            const double *__restrict__ kwtab, const double2 *__restrict__ grid,
                                                            double2 *__restrict__ sacc, const double *__restrict__ swgt,
@@ -871,7 +915,13 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_rw(GroupArgs ga, const Vi
 #pragma unroll
             for (int k = 0; k < KP; ++k) sr[k] = si[k] = 0.0;
             asm volatile("s_nop 1" : "+v"(ku));  // VALU write -> DPP read of the same register needs 2 wait states
-            rw_steps<KP, 0>(base, base2, ku, sr, si);
+            if constexpr (PD == 0) {
+                rw_steps0<KP, 0>(base, base2, ku, sr, si);
+            } else {
+                double2 cells[PD + 1][KP];
+                rw_prologue<KP, PD, 0>(base, base2, cells);
+                rw_steps<KP, PD, 0>(base, base2, ku, sr, si, cells);
+            }
             double tr = 0.0, ti = 0.0;
 #pragma unroll
             for (int k = 0; k < KP; ++k) {

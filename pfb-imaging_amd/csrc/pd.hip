@@ -157,13 +157,45 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
             off[size_t(b) + 1] = off[size_t(b)] + nparts[b];
         }
         auto blocks = [](size_t n) { return dim3(uint32_t(ceil_div(int64_t(n), 256))); };
+        // Stage clocks (HIP events on this stream, read back after the loop): Psi^H analysis, dual update, Psi synthesis, the
+        // PSF-approximate Hessian applies, primal step + norms -- what bench.py's C4 roofline is computed from.
+        struct StageClock {
+            hipStream_t st;
+            std::vector<hipEvent_t> ev;
+            std::vector<int> stage;
+            void begin(int s)
+            {
+                hipEvent_t a, b;
+                PFB_HIP(hipEventCreate(&a));
+                PFB_HIP(hipEventCreate(&b));
+                PFB_HIP(hipEventRecord(a, st));
+                ev.push_back(a);
+                ev.push_back(b);
+                stage.push_back(s);
+            }
+            void end() { PFB_HIP(hipEventRecord(ev.back(), st)); }
+            ~StageClock()
+            {
+                for (auto e : ev) (void)hipEventDestroy(e);
+            }
+        } clk{st, {}, {}};
+        const bool timed = info != nullptr && maxit <= 64;  // (bounded number of events: short, benchmark-style runs only)
+        auto tick = [&](int s) {
+            if (timed) clk.begin(s);
+        };
+        auto tock = [&]() {
+            if (timed) clk.end();
+        };
         double eps = 1.0;
         int k = 0, status = 1;
         const auto t_loop0 = std::chrono::steady_clock::now();  // (the stream is idle here: the uploads above were synchronised)
         PFB_HIP(hipStreamSynchronize(st));
         for (; k < maxit; ++k) {
+            tick(0);
             for (int64_t b = 0; b < nband; ++b) psi_dot_async(psi, xp + size_t(b) * npix, v + size_t(b) * cube);
+            tock();
             // v <- dual update(vp, Psi^H xp) ; vext <- 2 v - vp
+            tick(1);
             if (comm == nullptr) {
                 l21_fused_async(vp, v, vext.p, nband, int64_t(cube), lam, sigma, w.p, st);  // one pass over the cubes
             } else {
@@ -173,15 +205,22 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
                 PFB_CHECK_STATUS(pfbhip_comm_allreduce_sum(comm, sum.p, sum.p, int64_t(cube)));
                 l21_apply_async(vp, v, vext.p, nband, int64_t(cube), lam, sigma, w.p, sum.p, st);
             }
+            tock();
             for (int64_t b = 0; b < nband; ++b) {
                 double *xo = xout.p + size_t(b) * npix;
+                tick(2);
                 psi_hdot_async(psi, vext.p + size_t(b) * cube, xo);
+                tock();
                 hipLaunchKernelGGL(k_pd_diff, blocks(npix), dim3(256), 0, st, xt.p + size_t(b) * npix, xp + size_t(b) * npix, d.p,
                                    int64_t(npix));
-                for (int64_t q = off[size_t(b)]; q < off[size_t(b) + 1]; ++q)
+                for (int64_t q = off[size_t(b)]; q < off[size_t(b) + 1]; ++q) {
+                    tick(3);
                     psfconv_apply_async(pcs[b], d.p, psf_slots[q], beam_slots[q], 0, 0.0, -scale[b] / gamma,
                                         q == off[size_t(b)] ? -eta[b] / gamma : 0.0, 1, xo);
+                    tock();
+                }
             }
+            tick(4);
             const bool one_pass = !(positivity == 2 && comm != nullptr) && nband <= PD_MAXB;
             if (one_pass) {
                 hipLaunchKernelGGL(k_pd_step, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, st, int64_t(npix), int(nband), x, xp, xout.p, tau,
@@ -198,6 +237,7 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
                 }
                 hipLaunchKernelGGL(k_pd_norms, dim3(CG_BLOCKS), dim3(CG_THREADS), 0, st, int64_t(nimg), x, xp, partials.p);
             }
+            tock();
             PFB_HIP(hipGetLastError());
             PFB_HIP(hipMemcpyAsync(hpart.data(), partials.p, hpart.size() * sizeof(double), hipMemcpyDeviceToHost, st));
             PFB_HIP(hipStreamSynchronize(st));
@@ -241,6 +281,16 @@ int pfbhip_primal_dual(pfbhip_psi *psi, pfbhip_psfconv *const *pcs, int64_t nban
             info->status = status;
             info->eps = eps;
             info->loop_ms = loop_ms;
+            for (int q = 0; q < PFBHIP_PD_NSTAGES; ++q) {
+                info->stage_ms[q] = 0.0;
+                info->stage_calls[q] = 0;
+            }
+            for (size_t i = 0; i < clk.stage.size(); ++i) {
+                float ms = 0.f;
+                PFB_HIP(hipEventElapsedTime(&ms, clk.ev[2 * i], clk.ev[2 * i + 1]));
+                info->stage_ms[clk.stage[i]] += double(ms);
+                info->stage_calls[clk.stage[i]] += 1;
+            }
         }
     });
 }

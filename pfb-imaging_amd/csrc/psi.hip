@@ -383,6 +383,10 @@ struct pfbhip_psi {
             any_wavelet = any_wavelet || bases[size_t(b)] != 0;
         }
         const double *ident_used = any_wavelet ? ident : nullptr;
+        // The ride only works on a pass that OVERWRITES x (first == true: o = a + extra).  With a second identity basis in front
+        // of the first wavelet basis (bases = self, self, db1) that pass accumulates instead, and the slice is added by a copy
+        // kernel after the loop.
+        bool ident_added = ident_used == nullptr;
         for (int b = 0; b < nbasis; ++b) {
             const double *ab = alpha + size_t(b) * size_t(nxmax) * size_t(nymax);
             if (bases[size_t(b)] == 0) {
@@ -411,11 +415,17 @@ struct pfbhip_psi {
                                        img2(), size_t(ny), static_cast<const double *>(nullptr), size_t(0));
                 } else {
                     // (nxo == nx, nyo == ny at level 0: the pass covers the image)
+                    const double *extra = (first && !ident_added) ? ident_used : nullptr;
                     hipLaunchKernelGGL(k_idwt_rows, grid2((nyo + 1) / 2, nxo), dim3(256), 0, stream, cbuff.p, ldc, int(sy), w.rec, int(nyo),
-                                       first ? 0 : 1, x, size_t(ny), first ? ident_used : static_cast<const double *>(nullptr),
-                                       size_t(nymax));
+                                       first ? 0 : 1, x, size_t(ny), extra, size_t(nymax));
+                    if (extra != nullptr) ident_added = true;
                 }
             }
+            first = false;
+        }
+        if (!ident_added) {
+            hipLaunchKernelGGL(k_copy2d, grid2(ny, nx), dim3(256), 0, stream, ident_used, size_t(nymax), int(ny), first ? 0 : 1, x,
+                               size_t(ny));
             first = false;
         }
         PFB_HIP(hipGetLastError());

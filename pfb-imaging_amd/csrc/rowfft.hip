@@ -4,6 +4,7 @@
 #pragma clang fp contract(fast)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -14,8 +15,11 @@
 
 namespace pfbhip {
 
+// (load functors: two-step form, see rf_has_fetch in rowfft.hpp -- fetch() is the bare, branch-free request)
 struct PlainLoad {
     const double2 *row;
+    __device__ __forceinline__ double2 fetch(int i, int) const { return row[i]; }
+    __device__ __forceinline__ double2 finish(double2 v, int, int) const { return v; }
     __device__ __forceinline__ double2 operator()(int i, int) const { return row[i]; }
 };
 struct PlainStore {
@@ -28,10 +32,11 @@ struct PlainStore {
 struct RunLoad {
     const double2 *row;
     int4 r;
-    __device__ __forceinline__ double2 operator()(int i, int) const
-    {
-        return ((i >= r.x && i < r.y) || (i >= r.z && i < r.w)) ? row[i] : make_double2(0.0, 0.0);
-    }
+    __device__ __forceinline__ bool in(int i) const { return (i >= r.x && i < r.y) || (i >= r.z && i < r.w); }
+    // outside the runs: element 0 of the row (one hot line per wave), dropped by finish()
+    __device__ __forceinline__ double2 fetch(int i, int) const { return row[in(i) ? i : 0]; }
+    __device__ __forceinline__ double2 finish(double2 v, int i, int) const { return in(i) ? v : make_double2(0.0, 0.0); }
+    __device__ __forceinline__ double2 operator()(int i, int s) const { return finish(fetch(i, s), i, s); }
 };
 struct RunStore {
     double2 *row;
@@ -149,59 +154,123 @@ struct CropTStore {
 struct PadTLoad {
     const double2 *B;
     int u, nu, ny, nv, hy;
-    __device__ __forceinline__ double2 operator()(int v, int) const
+    __device__ __forceinline__ int yof(int v) const { return v < ny - hy ? v + hy : (v >= nv - hy ? v - (nv - hy) : -1); }
+    __device__ __forceinline__ double2 fetch(int v, int) const { return B[size_t(max(yof(v), 0)) * size_t(nu) + size_t(u)]; }
+    __device__ __forceinline__ double2 finish(double2 x, int v, int) const { return yof(v) >= 0 ? x : make_double2(0.0, 0.0); }
+    __device__ __forceinline__ double2 operator()(int v, int s) const { return finish(fetch(v, s), v, s); }
+};
+
+// L2 warm-up (round 3).  A row-FFT workgroup is the only one on its CU, and its time is (HBM time of its row at the share of
+// the bandwidth the workgroups in their I/O phase get) + (passes): the two do not overlap inside a CU, and over the chip they
+// ADD (a2b at C2: 2.8 GB at ~5 TB/s = 0.55 ms, + 0.65 ms of passes = the 1.2 ms measured).  Registers and LDS are full, so
+// the next row cannot be staged on chip; instead every workgroup, once its own requests are out, requests ONE dword per
+// 128-byte line of the row that the workgroup `ahead` positions later in dispatch order will transform -- the one that takes
+// this CU (and, block ids being dealt round robin, this XCD's L2) next -- and consumes the dwords after its passes.  The
+// next workgroup's requests then hit L2 / MALL while HBM streams under the passes.  ahead = CUs x workgroups per CU
+// (PFBHIP_RF_AHEAD overrides, 0 disables).
+struct RfTouch {
+    uint32_t v[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // (no arithmetic on these before consume(): it would wait for the data)
+    // lines [0, nlines) of `row` (128 bytes each), thread t of T takes lines t, t + T, ... into v[slot0 ...]; keep(l) = line wanted
+    template <int T, int NL, int SLOT0 = 0, class Keep>
+    __device__ __forceinline__ void row(const void *rowp, int nlines, int t, Keep &&keep)
     {
-        int y = -1;
-        if (v < ny - hy) y = v + hy;
-        else if (v >= nv - hy) y = v - (nv - hy);
-        return y >= 0 ? B[size_t(y) * size_t(nu) + size_t(u)] : make_double2(0.0, 0.0);
+        static_assert(SLOT0 + NL <= 8, "RfTouch holds eight dwords per thread");
+        const char *p = static_cast<const char *>(rowp);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int l = t + i * T;
+            if (l < nlines && keep(l)) v[SLOT0 + i] = *reinterpret_cast<const uint32_t *>(p + size_t(l) * 128);
+        }
+    }
+    __device__ __forceinline__ void consume() const
+    {
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
     }
 };
+static int rf_ahead(int wg_per_cu)
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const char *env = std::getenv("PFBHIP_RF_AHEAD");
+    return env != nullptr ? std::max(0, std::atoi(env)) : cus * wg_per_cu;
+}
 
 // blockIdx.y = plane of the launch (astride / bstride elements apart): one launch for all planes of a pass leaves one
 // partially filled round of workgroups instead of one per plane (4896 rows on 256 CUs: 19.1 rounds each)
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_a2b(const double2 *tw, const double2 *A, double2 *B,
                                                                           const int *rowmap, int nrows, int nu, int ny, size_t apitch,
-                                                                          size_t astride, size_t bstride, const int4 *colruns)
+                                                                          size_t astride, size_t bstride, const int4 *colruns, int ahead)
 {
     extern __shared__ double rf_lds[];
     if (int(blockIdx.x) >= nrows) return;
     const int u = rowmap[blockIdx.x];
+    // the workgroup `ahead` later in dispatch order (x fastest): its row is warmed below
+    const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x + uint32_t(ahead);
+    const uint32_t nxb = lin % gridDim.x, nyb = lin / gridDim.x;
+    const bool warm = ahead > 0 && nyb < gridDim.y && int(nxb) < nrows;
+    const int u2 = warm ? rowmap[nxb] : u;
+    const double2 *nrow = A + size_t(warm ? nyb : blockIdx.y) * astride + size_t(u2) * apitch;
+    const int4 r2 = colruns[u2 >> 5];
     A += size_t(blockIdx.y) * astride;
     B += size_t(blockIdx.y) * bstride;
     RunLoad ld{A + size_t(u) * apitch, colruns[u >> 5]};
     CropTStore st{B, u, nu, ny, S::N, ny / 2};
-    rf_row<S>(tw, ld, st, true, rf_lds);
+    RfTouch touch;
+    constexpr int NLINES = S::N / 8, NL = (NLINES + S::T - 1) / S::T;
+    const int tt = int(threadIdx.x);
+    auto hook = [&] {
+        if (warm)  // (column runs are whole 32-element tiles: a line lies inside a run or outside)
+            touch.template row<S::T, NL>(nrow, NLINES, tt, [&](int l) { return (8 * l >= r2.x && 8 * l < r2.y) || (8 * l >= r2.z && 8 * l < r2.w); });
+    };
+    if constexpr (S::WARM) rf_row<S>(tw, ld, st, true, rf_lds, hook);
+    else rf_row<S>(tw, ld, st, true, rf_lds);
+    touch.consume();
 }
 
 // Row u of Bt (tpitch elements per row, written by the fused pad kernel with the transpose in ITS stores): contiguous loads.
 struct PadRowLoad {
     const double2 *row;
     int ny, nv, hy;
-    __device__ __forceinline__ double2 operator()(int v, int) const
-    {
-        int y = -1;
-        if (v < ny - hy) y = v + hy;
-        else if (v >= nv - hy) y = v - (nv - hy);
-        return y >= 0 ? row[y] : make_double2(0.0, 0.0);
-    }
+    __device__ __forceinline__ int yof(int v) const { return v < ny - hy ? v + hy : (v >= nv - hy ? v - (nv - hy) : -1); }
+    __device__ __forceinline__ double2 fetch(int v, int) const { return row[max(yof(v), 0)]; }
+    __device__ __forceinline__ double2 finish(double2 x, int v, int) const { return yof(v) >= 0 ? x : make_double2(0.0, 0.0); }
+    __device__ __forceinline__ double2 operator()(int v, int s) const { return finish(fetch(v, s), v, s); }
 };
 
 template <class S, bool TR>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_b2a(const double2 *tw, const double2 *B, double2 *A,
                                                                           const int *rowmap, int nrows, int nu, int ny, size_t apitch,
-                                                                          int tpitch, size_t astride, size_t bstride, const int4 *colruns)
+                                                                          int tpitch, size_t astride, size_t bstride, const int4 *colruns,
+                                                                          int ahead)
 {
     extern __shared__ double rf_lds[];
     if (int(blockIdx.x) >= nrows) return;
     const int u = rowmap[blockIdx.x];
+    const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x + uint32_t(ahead);
+    const uint32_t nxb = lin % gridDim.x, nyb = lin / gridDim.x;
+    const bool warm = TR && ahead > 0 && nyb < gridDim.y && int(nxb) < nrows;
+    const int u2 = warm ? rowmap[nxb] : u;
+    const double2 *nrow = B + size_t(warm ? nyb : blockIdx.y) * bstride + size_t(u2) * size_t(tpitch);  // (Bt row of the next workgroup)
     A += size_t(blockIdx.y) * astride;
     B += size_t(blockIdx.y) * bstride;
     RunStore st{A + size_t(u) * apitch, colruns[u >> 5]};
     if constexpr (TR) {
         PadRowLoad ld{B + size_t(u) * size_t(tpitch), ny, S::N, ny / 2};
-        rf_row<S>(tw, ld, st, false, rf_lds);
+        RfTouch touch;
+        constexpr int NL = (S::N / 8 + S::T - 1) / S::T;  // (ny <= N lines at most)
+        const int tt = int(threadIdx.x), nlines = (ny + 7) / 8;
+        auto hook = [&] {
+            if (warm) touch.template row<S::T, NL>(nrow, nlines, tt, [](int) { return true; });
+        };
+        if constexpr (S::WARM) rf_row<S>(tw, ld, st, false, rf_lds, hook);
+        else rf_row<S>(tw, ld, st, false, rf_lds);
+        touch.consume();
     } else {
         PadTLoad ld{B, u, nu, ny, S::N, ny / 2};
         rf_row<S>(tw, ld, st, false, rf_lds);
@@ -216,7 +285,7 @@ static void launch_a2b(const RowFFTPlan &pl, const double2 *A, double2 *B, const
     rf_allow_lds(&k_rowfft_a2b<S>, &attr);
     // (grid.x a multiple of 8: a plane's workgroups then start on XCD 0 like the first plane's -- rowmap relies on it)
     hipLaunchKernelGGL((k_rowfft_a2b<S>), dim3(uint32_t((nrows + 7) / 8 * 8), uint32_t(nplanes)), dim3(S::T), size_t(S::LDS_BYTES),
-                       stream, pl.twiddle, A, B, rowmap, nrows, nu, ny, apitch, astride, bstride, colruns);
+                       stream, pl.twiddle, A, B, rowmap, nrows, nu, ny, apitch, astride, bstride, colruns, rf_ahead(S::WG_PER_CU));
 }
 template <class S>
 static void launch_b2a(const RowFFTPlan &pl, const double2 *B, double2 *A, const int *rowmap, int nrows, int nu, int ny,
@@ -227,12 +296,12 @@ static void launch_b2a(const RowFFTPlan &pl, const double2 *B, double2 *A, const
     if (tpitch > 0) {
         rf_allow_lds(&k_rowfft_b2a<S, true>, &attr_t);
         hipLaunchKernelGGL((k_rowfft_b2a<S, true>), grid, dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A, rowmap, nrows,
-                           nu, ny, apitch, tpitch, astride, bstride, colruns);
+                           nu, ny, apitch, tpitch, astride, bstride, colruns, rf_ahead(S::WG_PER_CU));
         return;
     }
     rf_allow_lds(&k_rowfft_b2a<S, false>, &attr);
     hipLaunchKernelGGL((k_rowfft_b2a<S, false>), grid, dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A, rowmap, nrows, nu,
-                       ny, apitch, 0, astride, bstride, colruns);
+                       ny, apitch, 0, astride, bstride, colruns, 0);
 }
 
 void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, const int *rowmap_dev, int nrows, int nu, int ny,
@@ -273,18 +342,25 @@ void rowfft_b2a(const RowFFTPlan &pl, const double2 *B_dev, double2 *A_dev, cons
 struct OccLoad {
     const double2 *row;
     uint64_t mask;
-    __device__ __forceinline__ double2 operator()(int u, int slot) const
-    {
-        return ((mask >> slot) & 1ull) ? row[u] : make_double2(0.0, 0.0);
-    }
+    __device__ __forceinline__ bool on(int slot) const { return ((mask >> slot) & 1ull) != 0; }
+    // unoccupied blocks were never written: request element 0 of the row instead (one hot line), dropped by finish()
+    __device__ __forceinline__ double2 fetch(int u, int slot) const { return row[on(slot) ? u : 0]; }
+    __device__ __forceinline__ double2 finish(double2 v, int, int slot) const { return on(slot) ? v : make_double2(0.0, 0.0); }
+    __device__ __forceinline__ double2 operator()(int u, int slot) const { return finish(fetch(u, slot), u, slot); }
 };
 
 // lds_row: the kernel keeps the running sum over the launch's planes of its image row in LDS (nx doubles
 // behind the transpose buffer) and touches accT once; otherwise (no room) every plane read-modify-writes accT.
+//
+// Memory requests are kept out of divergent control flow (round 3; see rf_has_fetch in rowfft.hpp): the row of B comes in
+// through OccLoad's branch-free fetch, and the epilogue of a plane that goes to the image requests the running sum, the
+// correction, the beam and x for two outputs at a time from clamped addresses, one group ahead of the group whose
+// screens are being evaluated; results wait in the registers of the transform and are stored after the last group (a
+// store between two request groups would make the compiler wait for it: loads and stores share the in-order vmcnt).
 template <class S, bool SC>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(const double2 *tw, FusedGeom g, const uint8_t *occ,
                                                           const double2 *B, size_t bstride, FusedPlanes planes,
-                                                          int do_w, int first, int lds_row, double *accT, FusedFinal fin)
+                                                          int do_w, int first, int lds_row, double *accT, FusedFinal fin, int ahead)
 {
     extern __shared__ double rf_lds[];
     double *acc = rf_lds + S::LDS_BYTES / sizeof(double);
@@ -292,11 +368,39 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
     double *arow = accT + size_t(y) * g.nx;
     uint64_t mask = 0;
     rf_for_each_load<S>(int(threadIdx.x), [&](int u, int slot) { mask |= (occ[u >> 5] ? 1ull : 0ull) << slot; });
+    // L2 warm-up (see RfTouch): during plane k the row of plane k + 1; during the last plane the first row of the workgroup
+    // that takes this CU next (image row y + ahead) and, when this launch finalizes, that row of corr / beam / x
+    constexpr int NLB = (S::N / 8 + S::T - 1) / S::T;
+    const int tt = int(threadIdx.x);
+    uint32_t wocc = 0;  // bit i: line tt + i T of a B row lies in an occupied 32-column block
+#pragma unroll
+    for (int i = 0; i < NLB; ++i)
+        if (tt + i * S::T < S::N / 8) wocc |= (occ[(tt + i * S::T) >> 2] ? 1u : 0u) << i;
+    const int y2 = (ahead > 0 && y + ahead < g.ny) ? y + ahead : -1;
     for (int k = 0; k < planes.kp; ++k) {
         OccLoad ld{B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch), mask};
         double re[S::E], im[S::E];
         int t;
-        rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
+        RfTouch touch;
+        auto hook = [&] {
+            const bool lastk = k + 1 == planes.kp;
+            if (ahead > 0 && (!lastk || y2 >= 0)) {
+                const double2 *nrow = lastk ? B + size_t(y2) * size_t(g.bpitch) : B + size_t(k + 1) * bstride + size_t(y) * size_t(g.bpitch);
+                touch.template row<S::T, NLB>(nrow, S::N / 8, tt, [&](int l) { return ((wocc >> ((l - tt) / S::T)) & 1u) != 0; });
+                if (lastk && fin.corr != nullptr) {
+                    constexpr int NLI = 8 - NLB < 3 ? 8 - NLB : 3;  // lines per thread over the three image rows (nx / 16 lines each)
+                    const size_t ro2 = size_t(y2) * size_t(g.nx);
+                    const int nli = g.nx / 16;
+                    touch.template row<S::T, NLI, NLB>(fin.corr + ro2, 3 * nli, tt, [&](int l) { return l < nli; });
+                    if (fin.beam != nullptr)
+                        touch.template row<S::T, NLI, NLB>(fin.beam + ro2 - size_t(nli) * 16, 3 * nli, tt, [&](int l) { return l >= nli && l < 2 * nli; });
+                    if (fin.x != nullptr)
+                        touch.template row<S::T, NLI, NLB>(fin.x + ro2 - size_t(2 * nli) * 16, 3 * nli, tt, [&](int l) { return l >= 2 * nli; });
+                }
+            }
+        };
+        if constexpr (S::WARM) rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im, hook);
+        else rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
         rf_opaque(t);
         const double wk = planes.w[k];
         double cc[FUSED_SCMAX], ss[FUSED_SCMAX];  // SC: this plane's composite screen polynomials
@@ -313,89 +417,109 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
         const bool add_lds = lds_row && k > 0;
         const bool add_img = lds_row ? (last && !first) : !(first && k == 0);
         const bool to_img = !lds_row || last;
-        // groups of four outputs: the running sums are requested first, the screens evaluated while they
-        // are in flight
-#pragma unroll
-        for (int e0 = 0; e0 < S::E; e0 += 4) {
-            double old[4], cf[4];
-            const bool finalize = last && to_img && fin.corr != nullptr;
-#pragma unroll
-            for (int e = e0; e < e0 + 4; ++e) {
-                const int ix = fg_ix(g, S::out_pos(t, e));
-                double o = 0.0, c = 1.0;
-                if (ix >= 0) {
-                    if (add_img) o = arow[ix];
-                    if (add_lds) o += acc[ix];
-                    if (finalize) {  // correction (and beam) requested together with the running sums
-                        const size_t oo = size_t(y) * size_t(g.nx) + size_t(ix);
-                        c = fin.corr[oo];
-                        if (fin.beam != nullptr) c *= fin.beam[oo];
-                    }
+        const bool finalize = last && to_img && fin.corr != nullptr;
+        // value of output e of this plane: Re( (im + i re) * (c - i s) ) (inverse transform: value = (im, re))
+        auto plane_value = [&](int e, int ix) {
+            double r = im[e];
+            if (do_w) {
+                double s, c;
+                if constexpr (SC) {
+                    fg_screen_poly(g, cc, ss, ix, y, s, c);
+                } else {
+                    double ph = wk * fg_t(g, ix, y);
+                    ph -= rint(ph);
+                    fg_sincos2pi(ph, s, c);
                 }
-                old[e - e0] = o;
-                cf[e - e0] = c;
+                r = im[e] * c + re[e] * s;
             }
+            return r;
+        };
+        if (!to_img) {  // running sum in LDS: no global memory in this epilogue
 #pragma unroll
-            for (int e = e0; e < e0 + 4; ++e) {
+            for (int e = 0; e < S::E; ++e) {
                 const int ix = fg_ix(g, S::out_pos(t, e));
                 if (ix >= 0) {
-                    double r = im[e];  // inverse transform: value = (im, re)
-                    if (do_w) {
-                        double s, c;
-                        if constexpr (SC) {
-                            fg_screen_poly(g, cc, ss, ix, y, s, c);
-                        } else {
-                            double ph = wk * fg_t(g, ix, y);
-                            ph -= rint(ph);
-                            fg_sincos2pi(ph, s, c);
-                        }
-                        r = im[e] * c + re[e] * s;  // Re( (im + i re) * (c - i s) )
-                    }
-                    r += old[e - e0];
-                    if (to_img) {
-                        if (finalize) {  // finalize in place of a separate pass over the image
-                            const size_t o = size_t(y) * size_t(g.nx) + size_t(ix);
-                            double v = r * cf[e - e0] * fin.scale;
-                            if (fin.x != nullptr) v += fin.eta * fin.x[o];
-                            fin.out[o] = v;
-                        } else {
-                            arow[ix] = r;
-                        }
-                    } else {
-                        acc[ix] = r;
-                    }
+                    double r = plane_value(e, ix);
+                    if (add_lds) r += acc[ix];
+                    acc[ix] = r;
                 }
+                if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the number of sincos chains in flight
             }
-            __builtin_amdgcn_sched_barrier(0);  // bound the number of sincos chains in flight
+            touch.consume();
+            continue;
         }
+        // rows the groups request from (always valid memory: absent arrays alias the accumulator row and are dropped)
+        const size_t ro = size_t(y) * size_t(g.nx);
+        const bool has_beam = finalize && fin.beam != nullptr, has_x = finalize && fin.x != nullptr;
+        const double *crow = finalize ? fin.corr + ro : arow;
+        const double *brow = has_beam ? fin.beam + ro : crow;
+        const double *xrow = has_x ? fin.x + ro : crow;
+        constexpr int GQ = 2;  // outputs per group (four: 64 VGPRs of requests in flight next to the 64 of the transform -- spills)
+        constexpr int NG = S::E / GQ;
+        double qi[2][GQ], qc[2][GQ], qb[2][GQ], qx[2][GQ];
+        auto request = [&](int e0, int buf) {
+#pragma unroll
+            for (int j = 0; j < GQ; ++j) {
+                const int ixc = max(fg_ix(g, S::out_pos(t, e0 + j)), 0);
+                qi[buf][j] = arow[ixc];
+                qc[buf][j] = crow[ixc];
+                qb[buf][j] = brow[ixc];
+                qx[buf][j] = xrow[ixc];
+            }
+        };
+        request(0, 0);
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) request(GQ * (gq + 1), (gq + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < GQ; ++j) {
+                const int e = GQ * gq + j;
+                const int ix = fg_ix(g, S::out_pos(t, e));
+                double v = 0.0;
+                if (ix >= 0) {
+                    double r = plane_value(e, ix);
+                    if (add_lds) r += acc[ix];
+                    if (add_img) r += qi[gq & 1][j];
+                    if (finalize) {  // finalize in place of a separate pass over the image
+                        const double c = has_beam ? qc[gq & 1][j] * qb[gq & 1][j] : qc[gq & 1][j];
+                        v = r * c * fin.scale;
+                        if (has_x) v += fin.eta * qx[gq & 1][j];
+                    } else {
+                        v = r;
+                    }
+                }
+                re[e] = v;  // (re[e] / im[e] are dead from here on)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        double *orow = finalize ? fin.out + ro : arow;
+#pragma unroll
+        for (int e = 0; e < S::E; ++e) {
+            const int ix = fg_ix(g, S::out_pos(t, e));
+            if (ix >= 0) orow[ix] = re[e];
+        }
+        touch.consume();
     }
 }
 
-template <bool SC>
+// Degridding side.  The prepared image row x * corr [* beam] lives in LDS across the planes (lds_row; filled by a pre-pass
+// whose requests -- three arrays, half the thread's pixels at a time -- are all in flight together), or, where it does not
+// fit, is read per plane from a PREPARED image (the caller ran k_prepare_img).  Either way the load functor's fetch is one
+// branch-free read and its finish the screen.
+template <bool SC, bool LROW>
 struct PadLoadT {
-    const double *drow;  // dcT row y (or, prep: the caller's image row)
-    const double *crow, *brow;  // prep: correction / beam rows (crow == NULL: drow is already prepared)
-    double *lrow;        // LDS copy of the row (NULL: none); plane 0 fills it, the others read it
+    const double *src;   // LROW: the LDS row; else row y of the prepared image
     const FusedGeom &g;  // the kernel argument itself (a copy would put the coefficient array in scratch)
     const double (&cc)[FUSED_SCMAX];  // SC: the plane's composite screen polynomials (registers of the kernel)
     const double (&ss)[FUSED_SCMAX];
-    int y, do_w, k;
+    int y, do_w;
     double wk;
-    __device__ __forceinline__ double2 operator()(int u, int) const
+    __device__ __forceinline__ double fetch(int u, int) const { return src[max(fg_ix(g, u), 0)]; }
+    __device__ __forceinline__ double2 finish(double val, int u, int) const
     {
         const int ix = fg_ix(g, u);
         if (ix < 0) return make_double2(0.0, 0.0);
-        double val;
-        if (lrow != nullptr && k > 0) {
-            val = lrow[ix];
-        } else {
-            val = drow[ix];
-            if (crow != nullptr) {
-                val *= crow[ix];
-                if (brow != nullptr) val *= brow[ix];
-            }
-            if (lrow != nullptr) lrow[ix] = val;  // thread-private cell: the same thread asks for it on every plane
-        }
         if (!do_w) return make_double2(val, 0.0);
         double s, c;
         if constexpr (SC) {
@@ -407,53 +531,110 @@ struct PadLoadT {
         }
         return make_double2(val * c, val * s);
     }
+    __device__ __forceinline__ double2 operator()(int u, int s) const { return finish(fetch(u, s), u, s); }
 };
 
-using PadLoad = PadLoadT<false>;
+using PadLoad = PadLoadT<false, false>;
 
 template <class S, bool SC>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const double2 *tw, FusedGeom g, const uint8_t *occ,
                                                          const double *dcT, FusedPrep prep, FusedPlanes planes, int do_w,
-                                                         int lds_row, double2 *B, size_t bstride)
+                                                         int lds_row, double2 *B, size_t bstride, int ahead)
 {
     extern __shared__ double rf_lds[];
-    double *lrow = lds_row ? rf_lds + S::LDS_BYTES / sizeof(double) : nullptr;
-    int y = blockIdx.x;
-    if (g.tpitch > 0 && y < (g.ny & ~63)) {
-        // transposed stores (below): the 8 rows y whose 16-byte pieces make up one 128-byte line of Bt go to 8 workgroups of
-        // ONE XCD (block ids equal mod 8) inside the same 64 block ids, so that the line leaves that XCD's L2 whole
-        const int r = y & 63;
-        y = (y & ~63) + (r & 7) * 8 + (r >> 3);
-    }
+    double *lrow = rf_lds + S::LDS_BYTES / sizeof(double);
+    // transposed stores (below): the 8 rows y whose 16-byte pieces make up one 128-byte line of Bt go to 8 workgroups of
+    // ONE XCD (block ids equal mod 8) inside the same 64 block ids, so that the line leaves that XCD's L2 whole
+    auto row_of = [&](int b) {
+        if (g.tpitch > 0 && b < (g.ny & ~63)) {
+            const int r = b & 63;
+            return (b & ~63) + (r & 7) * 8 + (r >> 3);
+        }
+        return b;
+    };
+    const int y = row_of(int(blockIdx.x));
+    const int y2 = (ahead > 0 && int(blockIdx.x) + ahead < g.ny) ? row_of(int(blockIdx.x) + ahead) : -1;  // (L2 warm-up, see RfTouch)
     uint32_t omask = 0;  // occupancy of the thread's output columns
 #pragma unroll
     for (int e = 0; e < S::E; ++e) omask |= (occ[S::out_pos(int(threadIdx.x), e) >> 5] ? 1u : 0u) << e;
-    for (int k = 0; k < planes.kp; ++k) {
-        const size_t ro = size_t(y) * size_t(g.nx);
-        double cc[FUSED_SCMAX], ss[FUSED_SCMAX];
+    const size_t ro = size_t(y) * size_t(g.nx);
+    if (lds_row) {
+        // pre-pass: lrow[ix] = x * corr [* beam] (or the prepared value) for the pixels this thread will be asked for
+        // (thread-private cells: the same thread reads them back on every plane, no barrier)
+        const bool raw = prep.x != nullptr, has_beam = raw && prep.beam != nullptr;
+        const double *xr = (raw ? prep.x : dcT) + ro;
+        const double *cr = raw ? prep.corr + ro : xr;
+        const double *br = has_beam ? prep.beam + ro : cr;
+        constexpr int NH = (S::NSLOT + 1) / 2;
 #pragma unroll
-        for (int q = 0; q < FUSED_SCMAX; ++q) {
-            cc[q] = SC ? planes.cs[k][q] : 0.0;
-            ss[q] = SC ? planes.sn[k][q] : 0.0;
-        }
-        PadLoadT<SC> ld{prep.x != nullptr ? prep.x + ro : dcT + ro, prep.x != nullptr ? prep.corr + ro : nullptr,
-                        (prep.x != nullptr && prep.beam != nullptr) ? prep.beam + ro : nullptr, lrow, g, cc, ss, y, do_w, k, planes.w[k]};
-        double re[S::E], im[S::E];
-        int t;
-        rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
-        rf_opaque(t);
-        if (g.tpitch > 0) {  // Bt[u][y]: the first-axis transform of row u then reads contiguously (k_rowfft_b2a<S, true>)
-            double2 *bcol = B + size_t(k) * bstride + size_t(y);
-#pragma unroll
-            for (int e = 0; e < S::E; ++e)
-                if ((omask >> e) & 1u) bcol[size_t(S::out_pos(t, e)) * size_t(g.tpitch)] = make_double2(re[e], im[e]);
-        } else {
-            double2 *brow = B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch);
-#pragma unroll
-            for (int e = 0; e < S::E; ++e)
-                if ((omask >> e) & 1u) brow[S::out_pos(t, e)] = make_double2(re[e], im[e]);
+        for (int h = 0; h < 2; ++h) {
+            double vx[NH], vc[NH], vb[NH];
+            rf_for_each_load<S>(int(threadIdx.x), [&](int u, int slot) {
+                if (slot / NH == h) {
+                    const int ixc = max(fg_ix(g, u), 0);
+                    vx[slot % NH] = xr[ixc];
+                    vc[slot % NH] = cr[ixc];
+                    vb[slot % NH] = br[ixc];
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            rf_for_each_load<S>(int(threadIdx.x), [&](int u, int slot) {
+                if (slot / NH == h) {
+                    const int ix = fg_ix(g, u);
+                    double v = vx[slot % NH];
+                    if (raw) v *= has_beam ? vc[slot % NH] * vb[slot % NH] : vc[slot % NH];
+                    if (ix >= 0) lrow[ix] = v;
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    auto planes_loop = [&](auto lrow_tag) {
+        constexpr bool LROW = decltype(lrow_tag)::value;
+        for (int k = 0; k < planes.kp; ++k) {
+            double cc[FUSED_SCMAX], ss[FUSED_SCMAX];
+#pragma unroll
+            for (int q = 0; q < FUSED_SCMAX; ++q) {
+                cc[q] = SC ? planes.cs[k][q] : 0.0;
+                ss[q] = SC ? planes.sn[k][q] : 0.0;
+            }
+            PadLoadT<SC, LROW> ld{LROW ? lrow : dcT + ro, g, cc, ss, y, do_w, planes.w[k]};
+            double re[S::E], im[S::E];
+            int t;
+            RfTouch touch;
+            auto hook = [&] {
+                if (k == 0 && y2 >= 0) {  // the image rows the next workgroup's pre-pass (or plane loop) reads: nx / 16 lines each
+                    const size_t ro2 = size_t(y2) * size_t(g.nx);
+                    const int nli = g.nx / 16, tt = int(threadIdx.x);
+                    const bool raw = prep.x != nullptr;
+                    touch.template row<S::T, 3, 0>((raw ? prep.x : dcT) + ro2, 3 * nli, tt, [&](int l) { return l < nli; });
+                    if (raw) {
+                        touch.template row<S::T, 3, 0>(prep.corr + ro2 - size_t(nli) * 16, 3 * nli, tt, [&](int l) { return l >= nli && l < 2 * nli; });
+                        if (prep.beam != nullptr)
+                            touch.template row<S::T, 3, 0>(prep.beam + ro2 - size_t(2 * nli) * 16, 3 * nli, tt, [&](int l) { return l >= 2 * nli; });
+                    }
+                }
+            };
+            if constexpr (S::WARM) rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im, hook);
+            else rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
+            rf_opaque(t);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g.tpitch > 0) {  // Bt[u][y]: the first-axis transform of row u then reads contiguously (k_rowfft_b2a<S, true>)
+                double2 *bcol = B + size_t(k) * bstride + size_t(y);
+#pragma unroll
+                for (int e = 0; e < S::E; ++e)
+                    if ((omask >> e) & 1u) bcol[size_t(S::out_pos(t, e)) * size_t(g.tpitch)] = make_double2(re[e], im[e]);
+            } else {
+                double2 *brow = B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch);
+#pragma unroll
+                for (int e = 0; e < S::E; ++e)
+                    if ((omask >> e) & 1u) brow[S::out_pos(t, e)] = make_double2(re[e], im[e]);
+            }
+            touch.consume();
+        }
+    };
+    if (lds_row) planes_loop(std::true_type{});
+    else planes_loop(std::false_type{});
 }
 
 void fused_geom_fit(FusedGeom &g)
@@ -610,10 +791,10 @@ struct OccLoad2 {
     const double2 *row;
     uint32_t mask;
     int par;
-    __device__ __forceinline__ double2 operator()(int pos, int slot) const
-    {
-        return ((mask >> slot) & 1u) ? row[2 * pos + par] : make_double2(0.0, 0.0);
-    }
+    __device__ __forceinline__ bool on(int slot) const { return ((mask >> slot) & 1u) != 0; }
+    __device__ __forceinline__ double2 fetch(int pos, int slot) const { return row[on(slot) ? 2 * pos + par : 0]; }
+    __device__ __forceinline__ double2 finish(double2 v, int, int slot) const { return on(slot) ? v : make_double2(0.0, 0.0); }
+    __device__ __forceinline__ double2 operator()(int pos, int slot) const { return finish(fetch(pos, slot), pos, slot); }
 };
 
 template <class S1>
@@ -681,6 +862,8 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
 struct PadLoad2 {
     PadLoad base;
     int par;
+    __device__ __forceinline__ double fetch(int pos, int slot) const { return base.fetch(2 * pos + par, slot); }
+    __device__ __forceinline__ double2 finish(double v, int pos, int slot) const { return base.finish(v, 2 * pos + par, slot); }
     __device__ __forceinline__ double2 operator()(int pos, int slot) const { return base(2 * pos + par, slot); }
 };
 
@@ -702,8 +885,7 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
     const size_t ro = size_t(y) * size_t(g.nx);
     const double zc[FUSED_SCMAX] = {};  // (the doubled shapes evaluate the screen the general way)
     for (int k = 0; k < planes.kp; ++k) {
-        PadLoad base{prep.x != nullptr ? prep.x + ro : dcT + ro, prep.x != nullptr ? prep.corr + ro : nullptr,
-                     (prep.x != nullptr && prep.beam != nullptr) ? prep.beam + ro : nullptr, nullptr, g, zc, zc, y, do_w, k, planes.w[k]};
+        PadLoad base{dcT + ro, g, zc, zc, y, do_w, planes.w[k]};  // (the doubled shapes read a PREPARED image: fused_pad_takes_prep)
         PadLoad2 ld_e{base, 0}, ld_o{base, 1};
         double er[S1::E], ei[S1::E], orr[S1::E], oi[S1::E];
         int t;
@@ -740,6 +922,7 @@ static void launch_pad2(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t 
                         hipStream_t stream)
 {
     static bool attr = false;
+    PFB_REQUIRE(prep.x == nullptr, "fused pad kernel of the doubled shapes needs a prepared image (fused_pad_takes_prep)");
     rf_allow_lds(&k_fused_pad_fft2<S1>, &attr);
     hipLaunchKernelGGL(k_fused_pad_fft2<S1>, dim3(uint32_t(g.ny)), dim3(S1::T), size_t(S1::LDS_BYTES), stream, pl.twiddle, g,
                        occ_dev, dcT_dev, prep, planes, do_w, B_dev, bstride);
@@ -766,12 +949,12 @@ static void launch_crop(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t 
     if (planes.nsc > 0 && do_w) {
         rf_allow_lds(&k_fused_fft_crop<S, true>, &attr_sc);
         hipLaunchKernelGGL((k_fused_fft_crop<S, true>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
-                           bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin);
+                           bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin, rf_ahead(S::WG_PER_CU));
         return;
     }
     rf_allow_lds(&k_fused_fft_crop<S, false>, &attr);
     hipLaunchKernelGGL((k_fused_fft_crop<S, false>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
-                       bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin);
+                       bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin, rf_ahead(S::WG_PER_CU));
 }
 
 template <class S>
@@ -780,17 +963,18 @@ static void launch_pad(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *
                        hipStream_t stream)
 {
     static bool attr = false, attr_sc = false;
-    const bool row = fused_row_fits(S::LDS_BYTES, g.nx) && planes.kp > 1;
+    const bool row = fused_row_fits(S::LDS_BYTES, g.nx);
+    PFB_REQUIRE(row || prep.x == nullptr, "fused pad kernel without an LDS row needs a prepared image (fused_pad_takes_prep)");
     const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
     if (planes.nsc > 0 && do_w) {
         rf_allow_lds(&k_fused_pad_fft<S, true>, &attr_sc);
         hipLaunchKernelGGL((k_fused_pad_fft<S, true>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
-                           prep, planes, do_w, row ? 1 : 0, B_dev, bstride);
+                           prep, planes, do_w, row ? 1 : 0, B_dev, bstride, rf_ahead(S::WG_PER_CU));
         return;
     }
     rf_allow_lds(&k_fused_pad_fft<S, false>, &attr);
     hipLaunchKernelGGL((k_fused_pad_fft<S, false>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
-                       prep, planes, do_w, row ? 1 : 0, B_dev, bstride);
+                       prep, planes, do_w, row ? 1 : 0, B_dev, bstride, rf_ahead(S::WG_PER_CU));
 }
 
 void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev, size_t bstride,
@@ -812,6 +996,18 @@ void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev,
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", f.pl.N);
     }
     PFB_HIP(hipGetLastError());
+}
+
+bool fused_pad_takes_prep(const RowFFT &f, const FusedGeom &g)
+{
+    if (!f.ok || f.pl.doubled) return false;
+    switch (f.pl.N) {
+#define RF_X(L, K) \
+    case (L << K): return fused_row_fits(RfShape<L, K, false>::LDS_BYTES, g.nx);
+        RF_FOR_SHAPES(RF_X)
+#undef RF_X
+        default: return false;
+    }
 }
 
 void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev, const FusedPrep &prep,

@@ -448,35 +448,83 @@ struct rf_load_from_lds : std::false_type {};
 template <class Load>
 struct rf_load_from_lds<Load, std::void_t<decltype(Load::FROM_LDS)>> : std::bool_constant<Load::FROM_LDS> {};
 
+// Two-step load functors.  A functor may split its work into
+//     Raw     fetch(int pos, int slot) const    the memory request alone: BRANCH-FREE (out-of-range positions read a
+//                                               clamped, valid address), no arithmetic on the result
+//     double2 finish(Raw, int pos, int slot)    zero padding, screens ... on the fetched word
+// and the transforms then issue EVERY request of the row before the first finish.  With the one-step form
+// (`cond ? row[i] : 0` inside operator()) hipcc puts each load behind its own branch and waits vmcnt(0) at the join:
+// the leading radix-5 pass of a 10240-point row made four dependent round trips to memory (one per butterfly), a
+// load -> multiply -> load chain one per element (ISA of round 2's kernels).
+template <class Load, class = void>
+struct rf_has_fetch : std::false_type {};
+template <class Load>
+struct rf_has_fetch<Load, std::void_t<decltype(std::declval<const Load &>().fetch(0, 0))>> : std::true_type {};
+template <class Load, bool = rf_has_fetch<Load>::value>
+struct rf_raw_type { using type = double2; };
+template <class Load>
+struct rf_raw_type<Load, true> { using type = decltype(std::declval<const Load &>().fetch(0, 0)); };
+template <class Load>
+__device__ __forceinline__ typename rf_raw_type<Load>::type rf_fetch(Load &ld, int pos, int slot)
+{
+    if constexpr (rf_has_fetch<Load>::value) return ld.fetch(pos, slot);
+    else return ld(pos, slot);
+}
+template <class Load>
+__device__ __forceinline__ double2 rf_finish(Load &ld, const typename rf_raw_type<Load>::type &raw, int pos, int slot)
+{
+    if constexpr (rf_has_fetch<Load>::value) return ld.finish(raw, pos, slot);
+    else return raw;
+}
+
 // Leading odd pass (radix M = 3 or 5, Ns = 1): N/M butterflies, ceil(E/M) per thread, inputs read
 // straight from the load functor, outputs written straight into the LDS transpose.
-template <int M, int E, bool DUAL, bool SWZ, int T, int N, int NL, class Load>
-__device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], int t, Load &ld, bool inverse, double *lds)
+// NB: butterflies whose requests are in flight together (two-step functors; RfShape::LOAD_BATCH: all of them where the
+// register budget allows, fewer in the 1024-thread shapes)
+struct RfNoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int M, int E, bool DUAL, bool SWZ, int T, int N, int NL, int NB, class Load, class Hook = RfNoHook>
+__device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], int t, Load &ld, bool inverse, double *lds,
+                                             Hook &&after_requests = Hook{})
 {
     constexpr int IT = (E + M - 1) / M;
     constexpr bool PRE = rf_load_from_lds<Load>::value;
+    constexpr bool BULK = PRE || rf_has_fetch<Load>::value;  // requests first (see rf_has_fetch)
+    constexpr int BATCH = PRE ? IT : (NB < 1 ? 1 : (NB > IT ? IT : NB));
     const int nbf = N / M;
     double *l2 = lds + NL;
     double oim[DUAL ? 1 : IT * M];
-    double2 vin[PRE ? IT * M : 1];
-    if constexpr (PRE) {
+    typename rf_raw_type<Load>::type vin[BULK ? IT * M : 1];
+    auto request = [&](int i) {
+        const int j = t + i * T;
+        // only the last butterfly of a thread can lie past the end (t + i T < N / M for i < IT - 1): it requests the
+        // thread's first butterfly again and drops it below -- no branch around the requests
+        const int jc = (i == IT - 1 && IT * T > N / M) ? (j < nbf ? j : t) : j;
 #pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int j = t + i * T;
+        for (int q = 0; q < M; ++q) vin[i * M + q] = rf_fetch(ld, jc + q * nbf, i * M + q);
+    };
+    if constexpr (BULK) {
 #pragma unroll
-            for (int q = 0; q < M; ++q) vin[i * M + q] = j < nbf ? ld(j + q * nbf, i * M + q) : make_double2(0.0, 0.0);
-        }
-        rf_barrier();
+        for (int i = 0; i < BATCH; ++i) request(i);
+        if constexpr (PRE) rf_barrier();
     }
+    after_requests();  // (the caller's L2 warm-up of the NEXT row: behind this row's requests in the in-order vmcnt queue)
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
+        if constexpr (BULK && BATCH < IT) {
+            if (i > 0 && i % BATCH == 0) {
+#pragma unroll
+                for (int i2 = i; i2 < i + BATCH && i2 < IT; ++i2) request(i2);
+            }
+        }
         const int j = t + i * T;
         double2 v[M] = {};
         if (j < nbf) {
 #pragma unroll
             for (int q = 0; q < M; ++q) {
                 double2 x;
-                if constexpr (PRE) x = vin[i * M + q];
+                if constexpr (BULK) x = rf_finish(ld, vin[i * M + q], j + q * nbf, i * M + q);
                 else x = ld(j + q * nbf, i * M + q);
                 v[q] = inverse ? make_double2(x.y, x.x) : x;
             }
@@ -560,6 +608,11 @@ struct RfShape {
     // (the fused kernels, ALLOW_DUAL = false, add their image row to the LDS: one workgroup per CU)
     static constexpr int WG_PER_CU = (ALLOW_DUAL && 2 * LDS_BYTES <= 160 * 1024 && 2 * T <= RF_TWO_WG_MAXT) ? 2 : 1;
     static constexpr int WAVES_PER_SIMD = (WG_PER_CU * ((T + 63) / 64) + 3) / 4;  // register budget = 512 / this
+    // leading odd pass: butterflies whose requests are in flight together (rf_first_odd): all of them at >= 168 VGPRs,
+    // about 14 complex words' worth at the 128 of a 1024-thread workgroup
+    static constexpr int LOAD_BATCH = WAVES_PER_SIMD <= 3 ? 64 : (LEAD_ >= 14 ? 1 : 14 / (LEAD_ > 1 ? LEAD_ : 1));
+    // L2 warm-up of the next row (kernels of rowfft.hip; costs the early twiddles' registers): not at the 128-VGPR budget
+    static constexpr bool WARM = WAVES_PER_SIMD <= 3;
     // position of the value left in slot e after the last pass
     static __device__ __forceinline__ int out_pos(int t, int e) { return t + rf_last_slot(RLAST, E, e) * T; }
 };
@@ -609,17 +662,69 @@ __device__ __forceinline__ void rf_passes(double (&re)[S::E], double (&im)[S::E]
 // stay live through it -- tens of VGPRs the passes need.
 __device__ __forceinline__ void rf_opaque(int &t) { asm volatile("" : "+v"(t)); }
 
+// The even (PAR = 0) / odd (PAR = 1) samples of a row as a load functor of the half-length transform (doubled shapes)
+template <class Load, int PAR, int SLOT0, bool = rf_has_fetch<Load>::value>
+struct RfHalfLoad {
+    Load &ld;
+    __device__ __forceinline__ double2 operator()(int pos, int slot) const { return ld(2 * pos + PAR, slot + SLOT0); }
+};
+template <class Load, int PAR, int SLOT0>
+struct RfHalfLoad<Load, PAR, SLOT0, true> {
+    Load &ld;
+    __device__ __forceinline__ auto fetch(int pos, int slot) const { return ld.fetch(2 * pos + PAR, slot + SLOT0); }
+    __device__ __forceinline__ double2 finish(const typename rf_raw_type<Load>::type &raw, int pos, int slot) const
+    {
+        return ld.finish(raw, 2 * pos + PAR, slot + SLOT0);
+    }
+    __device__ __forceinline__ double2 operator()(int pos, int slot) const { return ld(2 * pos + PAR, slot + SLOT0); }
+};
+
+// Every pass's twiddles of a thread, requested before anything else (rf_row_compute with a hook): the hook's requests then
+// sit BEHIND them in the in-order vmcnt queue and no later wait of the transform has to drain them.
+template <class S>
+struct RfTw {
+    double2 w[S::NP][S::E / 4];
+};
+template <class S, int P, int NS>
+__device__ __forceinline__ void rf_tw_load(RfTw<S> &tws, int t, const double2 *__restrict__ tw)
+{
+    constexpr int R = rf_radix(S::K, P);
+    if constexpr (NS > 1) {
+        double2 tmp[S::E / R];
+        rf_load_twiddles<R, S::E>(tmp, t, S::T, S::N, NS, tw);
+#pragma unroll
+        for (int i = 0; i < S::E / R; ++i) tws.w[P][i] = tmp[i];
+    }
+    if constexpr (P + 1 < S::NP) rf_tw_load<S, P + 1, NS * R>(tws, t, tw);
+}
+template <class S, int P, int NS>
+__device__ __forceinline__ void rf_passes_pre(double (&re)[S::E], double (&im)[S::E], int t, double *lds, const RfTw<S> &tws)
+{
+    constexpr int R = rf_radix(S::K, P);
+    double2 w1[S::E / R];
+#pragma unroll
+    for (int i = 0; i < S::E / R; ++i) w1[i] = tws.w[P][i];
+    rf_butterflies<R, S::E>(re, im, NS > 1, w1);
+    if constexpr (P + 1 < S::NP) {
+        rf_transpose<R, S::E, S::DUAL, S::SWZ, S::T, S::N, NS, S::xpad(R, NS), S::NL>(re, im, t, lds);
+        rf_passes_pre<S, P + 1, NS * R>(re, im, t, lds, tws);
+    }
+}
+
 // load -> passes; on return slot e holds the transform at position S::out_pos(t, e) as
 // (re[e], im[e]) for the forward transform and as (im[e], re[e]) for the (unnormalised) inverse.
-template <class S, class Load>
+// `after_requests` (plain shapes only): called once the row's own requests are out -- where a kernel warms the L2 with
+// the row its CU will take next; all twiddles are then requested up front (RfTw).
+template <class S, class Load, class Hook = RfNoHook>
 __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, Load &ld, bool inverse, double *lds,
-                                               int &t_out, double (&re)[S::E], double (&im)[S::E])
+                                               int &t_out, double (&re)[S::E], double (&im)[S::E], Hook &&after_requests = Hook{})
 {
+    constexpr bool HOOKED = !std::is_same<std::decay_t<Hook>, RfNoHook>::value;
     if constexpr (S::DOUBLED) {
         using S1 = typename S::S1;
         double er[S1::E], ei[S1::E], orr[S1::E], oi[S1::E];
-        auto ld_even = [&](int pos, int slot) { return ld(2 * pos, slot); };
-        auto ld_odd = [&](int pos, int slot) { return ld(2 * pos + 1, slot + S1::NSLOT); };
+        RfHalfLoad<Load, 0, 0> ld_even{ld};
+        RfHalfLoad<Load, 1, S1::NSLOT> ld_odd{ld};
         int t;
         rf_row_compute<S1>(tw, ld_even, inverse, lds, t, er, ei);
         __builtin_amdgcn_sched_barrier(0);
@@ -646,9 +751,22 @@ __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, L
     t_out = t;
     constexpr int R0 = rf_radix(S::K, 0);
     double2 w0[S::E / R0] = {};
+    RfTw<S> tws;
+    if constexpr (HOOKED) rf_tw_load<S, 0, S::LEAD>(tws, t, tw);
     if constexpr (S::LEAD > 1) {
-        rf_load_twiddles<R0, S::E>(w0, t, S::T, S::N, S::LEAD, tw);
-        rf_first_odd<S::LEAD, S::E, S::DUAL, S::SWZ, S::T, S::N, S::NL>(re, im, t, ld, inverse, lds);
+        if constexpr (!HOOKED) rf_load_twiddles<R0, S::E>(w0, t, S::T, S::N, S::LEAD, tw);
+        rf_first_odd<S::LEAD, S::E, S::DUAL, S::SWZ, S::T, S::N, S::NL, S::LOAD_BATCH>(re, im, t, ld, inverse, lds, after_requests);
+    } else if constexpr (rf_has_fetch<Load>::value) {
+        typename rf_raw_type<Load>::type raw[S::E];
+#pragma unroll
+        for (int e = 0; e < S::E; ++e) raw[e] = ld.fetch(t + e * S::T, e);
+        after_requests();
+#pragma unroll
+        for (int e = 0; e < S::E; ++e) {
+            const double2 x = ld.finish(raw[e], t + e * S::T, e);
+            re[e] = inverse ? x.y : x.x;
+            im[e] = inverse ? x.x : x.y;
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < S::E; ++e) {
@@ -657,12 +775,14 @@ __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, L
             im[e] = inverse ? x.x : x.y;
         }
     }
-    rf_passes<S, 0, S::LEAD>(re, im, t, tw, lds, w0);
+    if constexpr (HOOKED) rf_passes_pre<S, 0, S::LEAD>(re, im, t, lds, tws);
+    else rf_passes<S, 0, S::LEAD>(re, im, t, tw, lds, w0);
     }
 }
 
 // Calls f(pos, slot) for every element the load functor of rf_row_compute<S> will be asked for by
-// thread t, in the same order and with the same compile-time slot numbers (< 64).
+// thread t, in the same order and with the same compile-time slot numbers (< 64); slots of a butterfly past the end of the
+// row repeat positions of the thread's first butterfly (what rf_first_odd requests for them).
 template <class S, class F>
 __device__ __forceinline__ void rf_for_each_load(int t, F &&f)
 {
@@ -674,11 +794,10 @@ __device__ __forceinline__ void rf_for_each_load(int t, F &&f)
         constexpr int M = S::LEAD, IT = (S::E + M - 1) / M, nbf = S::N / M;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
-            const int j = t + i * S::T;
-            if (j < nbf) {
+            // (branch-free, like the transform's own requests: a last butterfly past the end repeats the thread's first one)
+            const int j = t + i * S::T, jc = (i == IT - 1 && IT * S::T > nbf) ? (j < nbf ? j : t) : j;
 #pragma unroll
-                for (int q = 0; q < M; ++q) f(j + q * nbf, i * M + q);
-            }
+            for (int q = 0; q < M; ++q) f(jc + q * nbf, i * M + q);
         }
     } else {
 #pragma unroll
@@ -687,13 +806,17 @@ __device__ __forceinline__ void rf_for_each_load(int t, F &&f)
 }
 
 // The whole row: load -> passes -> store.
-template <class S, class Load, class Store>
-__device__ __forceinline__ void rf_row(const double2 *__restrict__ tw, Load &ld, Store &st, bool inverse, double *lds)
+template <class S, class Load, class Store, class Hook = RfNoHook>
+__device__ __forceinline__ void rf_row(const double2 *__restrict__ tw, Load &ld, Store &st, bool inverse, double *lds,
+                                       Hook &&after_requests = Hook{})
 {
     double re[S::E], im[S::E];
     int t;
-    rf_row_compute<S>(tw, ld, inverse, lds, t, re, im);
+    rf_row_compute<S>(tw, ld, inverse, lds, t, re, im, after_requests);
     rf_opaque(t);
+    // No store before the last butterfly has consumed its twiddles: loads and stores share the in-order vmcnt, and behind
+    // a (conditional) store the compiler waits vmcnt(0) for them -- i.e. for the store's own round trip to memory.
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < S::E; ++e)
         st(S::out_pos(t, e), inverse ? make_double2(im[e], re[e]) : make_double2(re[e], im[e]));

@@ -81,6 +81,9 @@ void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev,
                     const FusedPlanes &pl, int do_w, bool first, double *accT_dev, const FusedFinal &fin, hipStream_t stream);
 // degrid side: for every image row y and plane k: B_k[y][wrap(x - nx/2)] = dcT[y][x] exp(+2 pi i w_k t), 0
 // elsewhere, forward row FFT, and only the occupied 32-column blocks of the result are written.
+// (prep.x != NULL only where fused_pad_takes_prep(): the kernel then keeps the prepared row in LDS; elsewhere -- no room for
+// the row, doubled shapes -- the caller passes a prepared image)
+bool fused_pad_takes_prep(const RowFFT &f, const FusedGeom &g);
 void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev, const FusedPrep &prep,
                    const FusedPlanes &pl, int do_w, double2 *B_dev, size_t bstride, hipStream_t stream);
 

@@ -183,9 +183,17 @@ uint64_t pfbhip_hash64(const void *data_host, size_t nbytes)
     if (nthr <= 1 || nchunks <= 1) {
         work(0, nchunks);
     } else {
+        // (no exception may cross the C ABI: a thread that cannot be created -- std::system_error under a process / thread
+        // limit -- leaves its share to this thread)
         std::vector<std::thread> th;
-        for (size_t t = 0; t < nthr; ++t) th.emplace_back(work, nchunks * t / nthr, nchunks * (t + 1) / nthr);
+        size_t started = 0;
+        try {
+            th.reserve(nthr);
+            for (; started < nthr; ++started) th.emplace_back(work, nchunks * started / nthr, nchunks * (started + 1) / nthr);
+        } catch (...) {
+        }
         for (auto &t : th) t.join();
+        if (started < nthr) work(nchunks * started / nthr, nchunks);
     }
     uint64_t h = mix(uint64_t(nbytes));
     for (size_t c = 0; c < nchunks; ++c) h = mix(h ^ part[c]) + 0x9E3779B97F4A7C15ull * (c + 1);

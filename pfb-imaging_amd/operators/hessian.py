@@ -66,8 +66,19 @@ def hessian_slice(x, xout=None, uvw=None, weight=None, vis_mask=None, freq=None,
         # whole device apply at 8192^2.  None keeps the reference's meaning: no normalisation / no Tikhonov term.
         direct = xout is not None and xout.dtype == np.float64 and xout.flags.c_contiguous and xout.shape == x.shape \
             and not np.shares_memory(xout, x)
-        convim = g.hessian(x, beam=beam, eta=0.0 if eta is None else float(eta), wsum=0.0 if wsum is None else float(wsum),
-                           out=xout if direct else None)
+        # The device call folds in a POSITIVE wsum only (it reads wsum <= 0 as "no normalisation").  The reference divides by
+        # whatever it is given (`if wsum is not None: convim /= wsum`, hessian.py:91-92): wsum = 0 there yields inf / nan, a
+        # negative one flips the sign -- those cases keep the reference's host arithmetic.
+        odd_wsum = wsum is not None and not (float(wsum) > 0.0)
+        if odd_wsum:
+            convim = g.hessian(x, beam=beam, eta=0.0, wsum=0.0, out=xout if direct else None)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                convim /= float(wsum)
+            if eta is not None:
+                convim += x * float(eta)
+        else:
+            convim = g.hessian(x, beam=beam, eta=0.0 if eta is None else float(eta), wsum=0.0 if wsum is None else float(wsum),
+                               out=xout if direct else None)
     finally:
         if not cached:
             g.close()

@@ -1,7 +1,7 @@
 """The backward (primal-dual) step of the SARA minor cycle on the GPU.
 
-Mirrors /root/reference/src/pfb_imaging/opt/primal_dual.py:303-448 (``PrimalDual``) and
-prox/l21.py:15-50 (``L21``).  When the gradient is the closure of the forward-backward splitting,
+Mirrors /root/reference/src/pfb_imaging/opt/primal_dual.py:303-448 (``PrimalDual``; the legacy ``primal_dual`` /
+``primal_dual_numba`` loops of :65-322 are here too), prox/l21.py:15-50 (``L21``) and prox/l1.py (``L1``).  When the gradient is the closure of the forward-backward splitting,
 ``grad(x) = -hess.dot(xtilde - x) / gamma`` (core/sara.py:288-289, deconv/pfb.py:158-161), expressed as a
 ``PsfGrad`` over a device-resident ``HessPSF``, and the dictionary is this package's ``Psi`` / ``PsiNocopyt``,
 ``solve`` runs the whole loop on the device (``pfbhip_primal_dual``: one scalar round trip per iteration).
@@ -79,6 +79,29 @@ class L21:
 
     def dual_update(self, vp, v, lam, sigma=1.0):
         dual_update_numba_fast(vp, v, lam, sigma=sigma, weight=self.l1weight)
+
+
+class L1:
+    """g(alpha) = ||W alpha||_1 (prox/l1.py:8-28): the image-domain regulariser (ISTA / lasso when ``psi`` is
+    ``IdentityPsi``).  Every band is thresholded on its own, which is the l21 prox of a one-band cube: the soft threshold runs
+    in the same device kernel as ``L21`` (``pfbhip_prox_21m`` with ``nband = 1`` per band of the cube)."""
+
+    def __init__(self, psi, nu=1.0):
+        for name in ("dot", "hdot", "nband", "nbasis", "nxmax", "nymax"):
+            if not hasattr(psi, name):
+                raise TypeError(f"psi does not satisfy the PsiOperator protocol (missing {name})")
+        self.psi = psi
+        self.nu = nu
+        self.weight = np.ones((psi.nbasis, psi.nymax, psi.nxmax))
+
+    def prox(self, v, vout, lam, sigma=1.0):
+        """vout = prox_{(lam / sigma) ||W .||_1}(v / sigma), in place on ``vout``."""
+        from .prox import prox_21m
+
+        v = np.asarray(v, dtype=np.float64)
+        w = np.broadcast_to(self.weight, v.shape[1:])
+        for b in range(v.shape[0]):  # one band at a time: the 2-norm over a single band is the absolute value
+            vout[b] = prox_21m(v[b:b + 1] / sigma, lam / sigma, weight=w)[0]
 
 
 class PsfGrad:
@@ -202,7 +225,8 @@ class PrimalDual:
             vall[local] = v
             vall = comm.allreduce_sum(vall).reshape(vfull.shape)
         self._v[...] = vall.transpose(0, 1, 3, 2) if transposed else vall
-        self.last = dict(iters=info.iters, status=info.status, eps=info.eps, loop_ms=float(info.loop_ms))
+        self.last = dict(iters=info.iters, status=info.status, eps=info.eps, loop_ms=float(info.loop_ms),
+                         stages={n: (float(info.stage_ms[i]), int(info.stage_calls[i])) for i, n in enumerate(_lib.PD_STAGE_NAMES)})
         x[...] = xall
         return x
 
@@ -250,6 +274,86 @@ class PrimalDual:
             np.copyto(vp, v)
         self.last = dict(iters=k, status=0 if eps < self.tol else 1, eps=eps)
         return x
+
+
+def primal_dual_numba(x, v, lam, psih, psi, hessnorm, prox, l1weight, reweighter, grad, nu=1.0, sigma=None, mask=None,
+                      tol=1e-5, maxit=1000, positivity=1, report_freq=10, gamma=1.0, verbosity=1, maxreweight=20):
+    """The legacy fused-kernel primal-dual loop with inner l1 reweighting (opt/primal_dual.py:153-322), returning ``(x, v)``.
+
+    Argument meaning follows the reference's BODY, not its parameter names: ``psi(image, coeffs_out)`` is the analysis and
+    ``psih(coeffs, image_out)`` the synthesis operator, both in place; ``prox`` and ``mask`` are accepted and unused;
+    ``reweighter(x)`` -- if given -- supplies new l1 weights whenever the inner loop converges, up to ``maxreweight``
+    consecutive times.  The dual update, positivity and (with this package's ``Psi``) the dictionary run on the GPU; the
+    reference's own test holds ``PrimalDual`` + ``L21`` to this trajectory (tests/test_primal_dual.py:57-105)."""
+    from .prox import positivity as clamp
+    from .prox import positivity_band as clamp_band
+
+    xp, vp, xout = x.copy(), v.copy(), np.zeros_like(x)
+    half = hessnorm / (2.0 * gamma)
+    if sigma is None:
+        sigma = half / nu
+    tau = 0.98 / (half + sigma * nu**2)
+    eps, run, last = 1.0, 0, 0
+    k = 0
+    for k in range(maxit):
+        psi(xp, v)
+        dual_update_numba_fast(vp, v, lam, sigma=sigma, weight=l1weight)
+        vp[...] = 2.0 * v - vp
+        psih(vp, xout)
+        xout += grad(xp)
+        x[...] = xp - tau * xout
+        if positivity == 1:
+            clamp(x)
+        elif positivity == 2:
+            clamp_band(x)
+        eps = float(np.sqrt(((x - xp) ** 2).sum() / max(float((x**2).sum()), 1e-12))) if _lib.any_nonzero(x) else 1.0
+        if eps < tol:
+            if reweighter is None or run >= maxreweight:
+                break
+            l1weight = reweighter(x)
+            run = run + 1 if k - last == 1 else 0
+            last = k
+        np.copyto(xp, x)
+        np.copyto(vp, v)
+        if verbosity > 1 and not k % report_freq:
+            print(f"At iteration {k} eps = {eps:.3e}")
+    if verbosity:
+        print(f"Max iters reached. eps = {eps:.3e}" if k == maxit - 1 else f"Success, converged after {k} iterations")
+    return x, v
+
+
+def primal_dual(x, v, lam, psi, psih, hessnorm, prox, grad, nu=1.0, sigma=None, mask=None, tol=1e-5, maxit=1000, minit=10,
+                positivity=1, report_freq=10, gamma=1.0, verbosity=1):
+    """The legacy allocating primal-dual loop (opt/primal_dual.py:65-150), returning ``(x, v)``.
+
+    Here ``psi(coeffs)`` is the SYNTHESIS and ``psih(image)`` the ANALYSIS operator, both returning new arrays, and
+    ``prox(v, lam)`` returns the prox of the regulariser; the step is ``tau = 0.9 / (hessnorm / 2 gamma + sigma nu^2)`` and the
+    loop runs at least ``minit`` iterations.  Pure composition of the caller's callables (GPU when they are this package's)."""
+    xp, vp = x.copy(), v.copy()
+    half = hessnorm / (2.0 * gamma)
+    if sigma is None:
+        sigma = half / nu
+    tau = 0.9 / (half + sigma * nu**2)
+    eps, k = 1.0, 0
+    while (eps > tol or k < minit) and k < maxit:
+        vtilde = v + sigma * psih(xp)
+        v = vtilde - sigma * prox(vtilde / sigma, lam / sigma)
+        x = xp - tau * (psi(2 * v - vp) + grad(xp))
+        if positivity == 1:
+            x[x < 0.0] = 0.0
+        elif positivity == 2:
+            x[:, np.any(x <= 0, axis=0)] = 0.0
+        eps = float(np.linalg.norm(x - xp) / np.linalg.norm(x))
+        xp[...] = x
+        vp[...] = v
+        if not np.isfinite(eps):
+            raise FloatingPointError(f"primal_dual: eps = {eps} at iteration {k}")  # (the reference drops into pdb here)
+        if verbosity > 1 and not k % report_freq:
+            print(f"At iteration {k} eps = {eps:.3e}")
+        k += 1
+    if verbosity:
+        print(f"Max iters reached. eps = {eps:.3e}" if k == maxit else f"Success, converged after {k} iterations")
+    return x, v
 
 
 def _pm_device(aop, imsize, b):

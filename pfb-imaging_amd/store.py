@@ -3,8 +3,8 @@
 
 The reference's ``load_band`` opens the ``.dt`` zarr store as an xarray DataTree and materialises, per band node, ``DIRTY``
 and, per partition child, ``UVW / WEIGHT / MASK / FREQ / BEAM`` (gridding inputs) and ``PSFHAT / BEAM / wsum`` (Hessian
-inputs).  Here every array is decoded STRAIGHT INTO a page-locked host buffer (`_lib.result_empty`) -- no intermediate
-pageable copy -- so the plan constructors and ``set_weights`` upload them at the PCIe rate, and ``abs(PSFHAT)`` (the form the
+inputs).  Here every array lands in a page-locked host buffer (`_lib.result_empty`) -- zarr chunks are decoded straight
+into it, see read_pinned -- so the plan constructors and ``set_weights`` upload them at the PCIe rate, and ``abs(PSFHAT)`` (the form the
 Hessians consume, band_worker.py:89-95) is formed in place in that buffer.
 
 A *store* is anything that maps node names to nodes; a *node* offers its arrays by name and its children:
@@ -46,14 +46,45 @@ def _node_children(node):
     return {k: v for k, v in getattr(node, "groups", lambda: [])()}  # zarr group
 
 
+_PURE_INDEXING_WRAPPERS = ("LazilyIndexedArray", "CopyOnWriteArray", "MemoryCachedArray", "ZarrArrayWrapper")
+
+
+def _unwrap_zarr(data, shape):
+    """The zarr array behind an xarray variable's ``_data``, or None.  xarray keeps a lazily indexed stack of wrappers there
+    (``MemoryCachedArray(CopyOnWriteArray(LazilyIndexedArray(ZarrArrayWrapper)))``); only wrappers that index without
+    changing values are looked through -- a CF-decoding wrapper (scale / offset / mask / endianness) ends the search -- and
+    the array found must have the variable's full shape (no pending selection)."""
+    obj = data
+    for _ in range(8):
+        if obj is None:
+            return None
+        if hasattr(obj, "get_basic_selection"):
+            return obj if tuple(getattr(obj, "shape", ())) == tuple(shape) else None
+        if type(obj).__name__ not in _PURE_INDEXING_WRAPPERS:
+            return None
+        nxt = getattr(obj, "array", None)
+        if nxt is None:
+            get = getattr(obj, "get_array", None)
+            if get is not None:
+                try:
+                    nxt = get()
+                except Exception:
+                    nxt = None
+            if nxt is None:
+                nxt = getattr(obj, "_array", None)
+        obj = nxt
+    return None
+
+
 def read_pinned(src, dtype=None):
     """Decode ``src`` (zarr array, xarray variable / DataArray, numpy array, anything with ``shape`` / ``dtype`` and
-    ``__getitem__``) into a page-locked buffer and return it as a numpy array.  zarr arrays decode chunk by chunk directly
-    into the buffer (``get_basic_selection(out=...)``); other sources are copied once."""
+    ``__getitem__``) into a page-locked buffer and return it as a numpy array.  zarr arrays -- given directly or found behind
+    an xarray variable's lazy-indexing wrappers (see _unwrap_zarr) -- decode chunk by chunk directly into the buffer
+    (``get_basic_selection(out=...)``); every other source (in-memory xarray variables, CF-decoded ones, numpy arrays) is
+    materialised by its owner and copied once."""
     var = getattr(src, "variable", src)
-    data = getattr(var, "_data", None)
-    zarr_like = data if hasattr(data, "get_basic_selection") else (src if hasattr(src, "get_basic_selection") else None)
     shape = tuple(src.shape)
+    zarr_like = src if hasattr(src, "get_basic_selection") else _unwrap_zarr(getattr(var, "_data", None), shape)
     dt = np.dtype(src.dtype if dtype is None else dtype)
     out = _lib.result_empty(shape, dt)
     if zarr_like is not None and np.dtype(zarr_like.dtype) == dt:

@@ -45,14 +45,18 @@ def test_struct_layout_matches_header(tmp_path):
         " offsetof(pfbhip_gridder_info, beta), offsetof(pfbhip_gridder_info, wmode),"
         " offsetof(pfbhip_gridder_info, device_bytes));\n"
         'printf("%zu %zu\\n", sizeof(pfbhip_cg_info), offsetof(pfbhip_cg_info, eps));\n'
+        'printf("%zu %zu %zu %d\\n", sizeof(pfbhip_pd_info), offsetof(pfbhip_pd_info, stage_ms),'
+        " offsetof(pfbhip_pd_info, stage_calls), PFBHIP_PD_NSTAGES);\n"
         "return 0;}\n"
     )
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
-    P, I, C = _lib.GridderParams, _lib.GridderInfo, _lib.CGInfo
+    P, I, C, D = _lib.GridderParams, _lib.GridderInfo, _lib.CGInfo, _lib.PDInfo
     expect = [ct.sizeof(P), P.epsilon.offset, P.flip_u.offset, P.force_wmode.offset, P.force_sigma.offset,
-              ct.sizeof(I), I.W.offset, I.beta.offset, I.wmode.offset, I.device_bytes.offset, ct.sizeof(C), C.eps.offset]
+              ct.sizeof(I), I.W.offset, I.beta.offset, I.wmode.offset, I.device_bytes.offset, ct.sizeof(C), C.eps.offset,
+              ct.sizeof(D), D.stage_ms.offset, D.stage_calls.offset, _lib.PD_NSTAGES]
+    assert len(_lib.PD_STAGE_NAMES) == _lib.PD_NSTAGES
     assert [int(v) for v in out] == expect
 
 
@@ -160,3 +164,54 @@ def test_content_hash_sees_every_byte():
     kv = _lib.content_key(view)
     base[3] += 1.0
     assert _lib.content_key(view) != kv
+    # an owner that flips `writeable` on, edits in place and flips it off again: the memo's sampled fingerprint notices
+    # (every word of a small array is sampled) and the entry is re-hashed
+    own = rng.standard_normal(2048)
+    own.flags.writeable = False
+    ko = _lib.content_key(own)
+    own.flags.writeable = True
+    own[1234] += 1.0
+    own.flags.writeable = False
+    assert _lib.content_key(own) != ko
+    # the memo is bounded by bytes as well as by entries
+    assert _lib._ro_memo_bytes[0] == sum(v[0].nbytes for v in _lib._ro_memo.values()) <= _lib._RO_MEMO_BYTES
+
+
+def test_pinned_results_are_capped(monkeypatch):
+    """Live page-locked result bytes are bounded (PFBHIP_PINNED_MAX_MB): past the cap result arrays are ordinary numpy
+    allocations.  (No GPU here: the allocator entry is replaced by one that records what it is asked for.)"""
+    import ctypes as ct
+
+    from pfb_imaging_amd import _lib
+
+    bufs = []
+
+    class FakeLib:
+        def pfbhip_host_alloc(self, pp, nbytes):
+            b = ct.create_string_buffer(nbytes.value)
+            bufs.append(b)
+            ct.cast(pp, ct.POINTER(ct.c_void_p))[0] = ct.addressof(b)
+            return 0
+
+        def pfbhip_host_free(self, p):
+            return 0
+
+    monkeypatch.setattr(_lib, "lib", lambda: FakeLib())
+    monkeypatch.setenv("PFBHIP_PINNED_RESULTS", "1")
+    monkeypatch.setenv("PFBHIP_PINNED_MAX_MB", "5")
+    monkeypatch.setattr(_lib, "_pinned_live", [0])
+    monkeypatch.setattr(_lib, "_pinned_pool", [])
+    monkeypatch.setattr(_lib, "_pinned_pooled", [0])
+    a = _lib.result_empty((2 << 20,), np.uint8)    # 2 MiB: pinned
+    b = _lib.result_empty((2 << 20,), np.uint8)    # 4 MiB live
+    assert len(bufs) == 2 and _lib._pinned_live[0] == 4 << 20
+    c = _lib.result_empty((2 << 20,), np.uint8)    # would be 6 MiB > 5: pageable
+    assert len(bufs) == 2 and c.shape == a.shape
+    del b                                           # back to the pool (still live), reused by the next request of that size
+    import gc
+
+    gc.collect()
+    d = _lib.result_empty((2 << 20,), np.uint8)
+    assert len(bufs) == 2 and _lib._pinned_live[0] == 4 << 20 and d.ctypes.data in (ct.addressof(x) for x in bufs)
+    del a, c, d
+    gc.collect()

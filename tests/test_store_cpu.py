@@ -62,3 +62,40 @@ def test_load_band_from_in_memory_stores(monkeypatch):
         if wrap is ZarrLike:  # decoded chunk by chunk straight into the staging buffer: no intermediate array
             z = s["band3"]["children"]["part0"]["arrays"]["UVW"]
             assert z.decoded_into is parts[0]["UVW"]
+
+
+def test_read_pinned_looks_through_xarray_lazy_wrappers(monkeypatch):
+    """An xarray variable opened from zarr keeps MemoryCachedArray(CopyOnWriteArray(LazilyIndexedArray(ZarrArrayWrapper)))
+    in ``_data`` (xarray.core.indexing / xarray.backends.zarr): read_pinned decodes the zarr array behind them straight
+    into the staging buffer, and stops at a value-changing (CF-decoding) wrapper, which it lets xarray materialise."""
+    monkeypatch.setenv("PFBHIP_PINNED_RESULTS", "0")
+    from pfb_imaging_amd import store as st
+
+    def wrapper(name, inner, attr="array"):
+        obj = type(name, (), {})()
+        if attr == "get_array":
+            obj.get_array = lambda: inner
+        else:
+            setattr(obj, attr, inner)
+        return obj
+
+    a = np.random.default_rng(1).standard_normal((23, 5))
+    z = ZarrLike(a)
+    data = wrapper("MemoryCachedArray", wrapper("CopyOnWriteArray", wrapper("LazilyIndexedArray",
+                                                                            wrapper("ZarrArrayWrapper", z, "get_array"))))
+
+    class Var:
+        def __init__(self, d):
+            self._data, self.shape, self.dtype, self.values = d, a.shape, a.dtype, a
+
+    out = st.read_pinned(Var(data))
+    assert z.decoded_into is out and np.array_equal(out, a)
+    # a decoding wrapper in the chain: not looked through (its values differ from the stored ones)
+    z2 = ZarrLike(a * 0 + 7.0)
+    decoded = wrapper("MemoryCachedArray", wrapper("_ElementwiseFunctionArray", wrapper("LazilyIndexedArray", z2)))
+    out2 = st.read_pinned(Var(decoded))
+    assert z2.decoded_into is None and np.array_equal(out2, a)
+    # a pending selection (shape mismatch): not looked through either
+    z3 = ZarrLike(np.zeros((40, 5)))
+    out3 = st.read_pinned(Var(wrapper("LazilyIndexedArray", z3)))
+    assert z3.decoded_into is None and np.array_equal(out3, a)
