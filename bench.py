@@ -43,6 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+F64_PEAK_TFLOPS = 78.6  # f64 vector FMA: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (the chip holds ~2.0 GHz under this load)
 # stage timer -> the kernel it brackets (name as rocprofv3 lists it); the record scatter / row-walk gather / transposing
 # first-axis FFT replace k_grid_blk / k_degrid_mp / k_rowfft_plain + k_a2b / k_b2a where the plan admits them
 KERNEL_OF = {"grid": "k_grid_rec", "degrid": "k_degrid_rw", "fft_rows": "k_rowfft_a2b / k_rowfft_b2a", "pad": "k_b2a",
@@ -307,8 +308,11 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
     solve = args.config == "C3"
     cfg = "C2" if solve else args.config
     # ---- this rank's band -------------------------------------------------
+    # C5 on N > 1 GPUs: ONE band split by |w| over the ranks (parallel.WShardedGridder: every rank stacks only the w-planes of
+    # its range; the partial images are all-reduced inside every apply) -- strong scaling of the single-band stress config
+    split = cfg == "C5" and world > 1
     if cfg in synth.CONFIGS:
-        case = synth.make_config(cfg, band=rank, with_vis=(world == 1 and cfg in ("C1", "C2")))
+        case = synth.make_config(cfg, band=0 if split else rank, with_vis=(world == 1 and cfg in ("C1", "C2")))
         nrow_c, nchan_c, npix_c, _ = synth.CONFIGS[cfg]
         what = "per-band PCG solve (on-device CG around the exact Hessian) + RCCL reduce of the image" if solve else \
             "exact Hessian apply (degrid+FFT+grid)"
@@ -323,11 +327,22 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
         size_txt = f"{npix}^2 grid, {nrow * nchan:.0e} vis/band".replace("e+0", "e")
     nx, ny = case["nx"], case["ny"]
     t0 = time.time()
-    g = Gridder(case["uvw"], case["freq"], case["mask"], npix_x=nx, npix_y=ny, pixsize_x=case["cell"],
-                pixsize_y=case["cell"], center_x=0.0, center_y=0.0, epsilon=args.epsilon, flip_u=False, flip_v=True,
-                flip_w=False, do_wgridding=True, divide_by_n=False, sigma_min=1.1, sigma_max=3.0, verbosity=args.verbosity,
-                force=None if args.force is None else (float(args.force.split(",")[0]), int(args.force.split(",")[1])))
-    g.set_weights(case["wgt"])
+    gkw = dict(npix_x=nx, npix_y=ny, pixsize_x=case["cell"], pixsize_y=case["cell"], center_x=0.0, center_y=0.0, epsilon=args.epsilon,
+               flip_u=False, flip_v=True, flip_w=False, do_wgridding=True, divide_by_n=False, sigma_min=1.1, sigma_max=3.0,
+               verbosity=args.verbosity,
+               force=None if args.force is None else (float(args.force.split(",")[0]), int(args.force.split(",")[1])))
+    planes_per_rank = None
+    if split:
+        from pfb_imaging_amd.parallel import WShardedGridder
+
+        wsg = WShardedGridder(comm, case["uvw"], case["freq"], case["mask"], **gkw)
+        wsg.set_weights(case["wgt"])
+        g = wsg.local
+        planes_per_rank = wsg.planes_per_rank()
+        wl = wl.replace("1 band/GPU", f"ONE band split by |w| over {world} GPUs")
+    else:
+        g = Gridder(case["uvw"], case["freq"], case["mask"], **gkw)
+        g.set_weights(case["wgt"])
     t_plan = time.time() - t0
     info = g.info
     wsum = float(case["wgt"][case["mask"] != 0].sum())
@@ -354,13 +369,19 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
         def step():
             g.hessian_dev(x_dev, out_dev, eta=0.0, wsum=wsum)
             nstep[0] += 1
-            if use_rccl and nstep[0] % reduce_every == 0:
+            if split:  # the partial images of the |w| ranges are summed inside EVERY apply (the operator's own exchange step)
+                if use_rccl:
+                    comm.allreduce_sum_dev(out_dev, out_dev)
+            elif use_rccl and nstep[0] % reduce_every == 0:
                 comm.reduce_sum_dev(out_dev, red_dev, root=0)
 
         for _ in range(args.warmup):
             step()
         if use_rccl:  # warm the communicator (first-call setup is not part of a step)
-            comm.reduce_sum_dev(out_dev, red_dev, root=0)
+            if split:
+                comm.allreduce_sum_dev(out_dev, out_dev)
+            else:
+                comm.reduce_sum_dev(out_dev, red_dev, root=0)
         nstep[0] = 0
     comm.barrier()
     _lib.check(_lib.lib().pfbhip_synchronize())
@@ -391,6 +412,16 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
         stage_launches = {s: v[1] / args.steps for s, v in stages.items()}
         actual = sum(per_launch[s] * stages[s][1] / args.steps for s in per_launch if stages[s][1]) + other_bytes
         apply_s = elapsed / args.steps
+        pmc, pmc_file = {}, None
+        import glob
+
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        if cands:
+            try:
+                pmc = json.load(open(cands[-1]))
+                pmc_file = os.path.relpath(cands[-1], ROOT) + " (separate rocprofv3 --pmc passes of this command)"
+            except Exception:
+                pmc = {}
         names = dict(KERNEL_OF)
         if info["scatter_mode"] != 2:
             names["grid"] = "k_grid_blk" if info["scatter_mode"] == 1 else "k_grid_mp"
@@ -403,21 +434,23 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
             f"Mvis/s gridded+degridded inside per-band PCG solves ({size_txt}, one band per GPU, RCCL reduce of the image)"
         out = {
             "metric": metric,
-            "value": total_active * 2 / apply_s / 1e6,
+            "value": total_active * 2 / apply_s / 1e6,   # (split: the ranks' active visibilities add up to the one band's)
             "unit": "Mvis/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if split else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "hessian_applies_per_s": world / apply_s,
+            "hessian_applies_per_s": (1 if split else world) / apply_s,
             "rccl_ranks": world if use_rccl else 0,
             "config": {
-                "workload": wl, "bands": world,
+                "workload": wl, "bands": 1 if split else world,
+                **({"w_planes_per_rank": planes_per_rank, "split": "contiguous |w| ranges (parallel.partition_rows_by_w), one "
+                    "all-reduce of the image per apply"} if split else {}),
                 "w_scheme": "polynomial planes" if info["wmode"] == 1 else "ES-kernel planes",
                 "vis_per_band": int(case["uvw"].shape[0] * case["freq"].size), "active_vis_per_band": int(g.nactive),
                 "image": [nx, ny], "epsilon": args.epsilon, "grid": [info["nu"], info["nv"]], "occupied_rows": info["occ_rows"],
@@ -428,16 +461,20 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
                 (" + fused second axis" if info["fft_mode"] & 2 else
                  (" + own second axis (unfused)" if info["fft_mode"] & 4 else " + rocFFT second axis")),
                 "sigma": info["sigma"],
-                "parallelism": f"band-per-gpu x{world}" + (
+                "parallelism": (f"one band, |w| ranges x{world} + 1 RCCL all-reduce of the image per apply" if split and use_rccl else
+                                f"one band, |w| ranges x{world} (image all-reduce skipped: {rccl_error})" if split else
+                                f"band-per-gpu x{world}") + ("" if split else (
                     (f" + 1 RCCL sum-to-root of the image per {'solve' if solve else str(reduce_every) + ' applies'}") if use_rccl else
-                    (f" (band reduce skipped: {rccl_error})" if rccl_error else "")),
+                    (f" (band reduce skipped: {rccl_error})" if rccl_error else ""))),
                 "plan_seconds": round(t_plan, 2),
             },
             "roofline": {
                 "bound": "hbm", "kernel": names.get(dom, dom), "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                # not measured in this run: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) are separate runs, see profiles/
-                "traffic": None, "traffic_profile": "profiles/r02f_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
+                # HBM bytes per launch of this stage from the PMC counters: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+                # this same command (tools/final_profile.sh -> tools/pmc_traffic.py, gfx950 FETCH_SIZE x 2 correction), read from
+                # the newest tracked profile of the default workload; null for other workloads or when no profile is tracked
+                "traffic": pmc.get(dom) if cfg == "C2" and not solve else None, "traffic_profile": pmc_file,
                 "alg_bytes_per_launch": per_launch[dom], "avg_launch_ms": avg_ms, "launches": dom_calls,
                 "actual_bytes_per_apply": actual,
                 "actual_frac": actual / apply_s / 1e9 / HBM_PEAK_GBS,
@@ -464,10 +501,20 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
                 nr -= 1
             f64_ops = nr * (1 + 2 * kp) + 14
             nsl = max(int(info["scatter_launches"]), 1)
-            floor_ms = g.nactive * f64_ops * 4 / (256 * 4) / 2.4e9 * 1e3 / nsl   # per launch
+            clock_ghz = 2.0   # what the chip holds under f64 load (tools/ubench.cpp: clock64 / wall = 1.96 GHz), not the 2.4 GHz peak
+            floor_ms = g.nactive * f64_ops * 4 / (256 * 4) / (clock_ghz * 1e9) * 1e3 / nsl   # per launch
+            # The stage is bound by f64 VALU issue, not by HBM: the headline figures of the object say so --
+            # achieved = f64 lane-operations the kernel must issue per launch (f64_ops wave instructions x 64 lanes x 2 flop per
+            # visibility, zero-cell FMAs of the block footprint included) / the launch time, against the f64 vector peak; the HBM
+            # figures the contract defines move to `hbm`.
+            r = out["roofline"]
+            r["hbm"] = {"achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"]}
+            flops = g.nactive / nsl * f64_ops * 128.0
+            r.update({"bound": "valu_f64", "achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": flops / (avg_ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS})
             out["roofline"]["limiter"] = {
                 "bound": "valu_f64", "f64_wave_instr_per_vis": f64_ops, "cycles_per_instr": 4, "simds": 1024,
-                "clock_ghz": 2.4, "launches_per_pass": nsl, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
+                "clock_ghz": clock_ghz, "launches_per_pass": nsl, "floor_ms": floor_ms, "frac": floor_ms / avg_ms,
                 "note": "counted f64 FMA/MUL only; a wave issues one instruction of any kind per 4 cycles, so scalar / LDS / "
                         "wait instructions cost issue slots too (tools/stamp_scatter.py: in-kernel phase stamps)",
             }
@@ -533,6 +580,54 @@ def bench_c4(args, comm, use_rccl, rccl_error):
     out = None
     if rank == 0:
         per = loop_s / args.steps
+        # ---- roofline of the dominant stage (stage clocks of pfbhip_primal_dual: HIP events on the loop's stream) ----
+        I = n * n * 8
+        nyo2 = npsf // 2 + 1
+        nwav = sum(1 for b in bases if b != "self")
+        levels = sum(0.25**l for l in range(nlevel))
+        # compulsory bytes per bracketed launch:
+        #  psf_hessian  one PSF-approximate Hessian apply of one band, pruned pipeline: x, beam read + T2 written | T2, |psfhat|
+        #               read + T1 written | T1, beam, x read + out written  = 6 I + 4 nx nyo2 16 + nxp nyo2 8
+        #  psi_analysis Psi^H of every local band: identity 2 I; per wavelet basis and level two passes of ~2 I / 4^l read + written
+        #  psi_synthesis one band: the mirror image (+ the image written once)
+        #  dual_update  vp, v read, v, vext written over the coefficient cubes (+ the weights once)
+        #  primal_step  x, xp, xout read, x written
+        cube = len(bases) * psi.nxmax * psi.nymax * 8
+        nloc = len([b for b in range(nband) if b % world == rank])
+        stage_bytes = {
+            "psf_hessian": 6 * I + 4 * n * nyo2 * 16 + npsf * nyo2 * 8,
+            "psi_analysis": nloc * (2 * I * (len(bases) - nwav) + nwav * 4 * I * levels + cube),
+            "psi_synthesis": 2 * I * (len(bases) - nwav) + nwav * 4 * I * levels + I,
+            "dual_update": nloc * 4 * cube + cube,
+            "primal_step": nloc * 4 * I,
+        }
+        stages = last.get("stages", {})
+        timed = {k: v for k, v in stages.items() if v[1] > 0}
+        roof = None
+        if timed:
+            dom = max(timed, key=lambda k: timed[k][0])
+            avg_ms = timed[dom][0] / timed[dom][1]
+            ach = stage_bytes[dom] / (avg_ms * 1e-3) / 1e9
+            Xr, Xc = npsf * npsf * 8, npsf * nyo2 * 16
+            roof = {"bound": "hbm", "stage": dom,
+                    "kernel": {"psf_hessian": "k_psf_rows_fwd + k_psf_cols + k_psf_rows_inv", "psi_analysis": "k_dwt_rows / k_dwt_cols",
+                               "psi_synthesis": "k_idwt_cols / k_idwt_rows", "dual_update": "k_l21_fused", "primal_step": "k_pd_step"}[dom],
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "alg_bytes_per_launch": stage_bytes[dom], "avg_launch_ms": avg_ms, "launches": timed[dom][1],
+                    "survey_bytes_per_launch": (6 * I + 3 * Xr + 6.5 * Xc) if dom == "psf_hessian" else None,
+                    "survey_note": "SURVEY.md section 8(d) UNPRUNED B_psf = 6 I + 3 Xr + 6.5 Xc (full padded r2c / c2r); the pipeline "
+                                   "that runs never stores outside the nx x (nyp/2+1) corner: alg_bytes_per_launch",
+                    "stage_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in stages.items()},
+                    "stage_launches_per_step": {k: v[1] / args.steps for k, v in stages.items()},
+                    "stage_achieved_gbs": {k: round(stage_bytes[k] / (v[0] / v[1] * 1e-3) / 1e9, 1) for k, v in timed.items()},
+                    "iteration_bytes": sum(stage_bytes[k] * v[1] / args.steps for k, v in timed.items()),
+                    "iteration_frac": sum(stage_bytes[k] * v[1] / args.steps for k, v in timed.items()) / per / 1e9 / HBM_PEAK_GBS}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline_c4(n, npsf, bases, nlevel, psfhat[0], eta[0], xtilde[0], model[0])
+            except Exception as e:
+                cpu = {"value": None, "unit": "Hessian-applies/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
         out = {
             "metric": "PSF-approximate Hessian applies/s inside the SARA primal-dual step (4 bands, 4096^2, Psi: self+db1+db2+db3, 3 levels)",
             "value": nband / per, "unit": "Hessian-applies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -546,7 +641,40 @@ def bench_c4(args, comm, use_rccl, rccl_error):
                        "parallelism": f"bands b % {world}" + (" + 1 RCCL all-reduce of the band sum and 1 of the norms per iteration"
                                                               if use_rccl else (f" (RCCL skipped: {rccl_error})" if rccl_error else ""))},
         }
+        if roof is not None:
+            out["roofline"] = roof
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
     return out
+
+
+def cpu_baseline_c4(n, npsf, bases, nlevel, psfhat0, eta0, xtilde0, model0):
+    """The oracle's restatement (oracle/psi.py + oracle/fftconv.py: numpy, one thread) of ONE primal-dual iteration on ONE of
+    the four bands -- a bounded sample; the bands are independent except for the l21 band sum, so the four-band iteration is
+    four times this."""
+    from oracle import fftconv
+    from oracle import psi as opsi
+
+    o = opsi.Psi(1, n, n, bases, nlevel)
+    x = model0[None].copy()
+    v = np.zeros((1, o.nbasis, o.nxmax, o.nymax))
+    vp = np.zeros_like(v)
+    w = np.ones(v.shape[1:])
+    xout = np.zeros_like(x)
+    t0 = time.perf_counter()
+    o.dot(x, v)
+    opsi.dual_update(vp, v, 0.01, 0.5, w)
+    vext = 2.0 * v - vp
+    o.hdot(vext, xout)
+    xout -= fftconv.hess_psf_dot(xtilde0[None] - x, psfhat0[None], npsf, beam=None, eta=eta0)
+    xn = x - 0.3 * xout
+    opsi.positivity(xn)
+    float(np.sqrt(((xn - x) ** 2).sum() / max((xn**2).sum(), 1e-12)))
+    t = time.perf_counter() - t0
+    return {"value": 1.0 / t, "unit": "Hessian-applies/s", "cores": 1, "kind": "port",
+            "sample": f"one primal-dual iteration of one band (of 4): Psi^H, dual update, Psi, PSF Hessian, primal step, positivity; "
+                      f"{t:.1f} s measured; numpy restatement on one thread -- the repository's oracle, not the reference's numba / ducc0 speed",
+            "sec_per_band_iteration": t}
 
 
 if __name__ == "__main__":

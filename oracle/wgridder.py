@@ -216,14 +216,16 @@ def choose_params(uvw, freq, mask, nx, ny, px, py, center_x, center_y, epsilon, 
     tmax = max(abs(nm1max + nshift), abs(nm1min + nshift))
     wlo, whi = w_range(uvw, freq, mask, flip_w) if do_wgridding else (0.0, 0.0)
     nvis = uvw.shape[0] * freq.size
-    eps1 = epsilon / (3.0 if do_wgridding else 2.0)
+    # (admissibility on the worst-sub-cell-position error with the product's margins, see choose_kernel in csrc/gridder.hip)
+    eps_w = epsilon / 3.0
+    eps1 = 0.8 / 1.25 * epsilon / (3.0 if do_wgridding else 2.0)
     best = None
     for r in kernel_table():
         if force is not None:
             if not (abs(r["sigma"] - force[0]) < 1e-9 and r["W"] == force[1]):
                 continue
         else:
-            if r["sigma"] < sigma_min - 1e-9 or r["sigma"] > sigma_max + 1e-9 or r["eps_max"] > eps1:
+            if r["sigma"] < sigma_min - 1e-9 or r["sigma"] > sigma_max + 1e-9 or r.get("eps_sup", r["eps_max"]) > eps1:
                 continue
         nu, nv = grid_size(nx, r["sigma"]), grid_size(ny, r["sigma"])
         for wmode in ((0, 1) if (do_wgridding and tmax > 0 and force_wmode is None) else
@@ -235,7 +237,7 @@ def choose_params(uvw, freq, mask, nx, ny, px, py, center_x, center_y, epsilon, 
                     touched = r["W"]
                 else:
                     dw = 1.0
-                    npl = cheb_planes_needed(2.0 * np.pi * 0.5 * (whi - wlo) * tmax, 2.0 * eps1)
+                    npl = cheb_planes_needed(2.0 * np.pi * 0.5 * (whi - wlo) * tmax, 2.0 * eps_w)
                     if npl is None:
                         continue
                     touched = npl

@@ -12,7 +12,8 @@ struct KernelRow {
     int W;
     double sigma, beta;
     double eps;      // 1-D aliasing error, L2 average over the image
-    double eps_max;  // 1-D aliasing error at the image edge (its maximum)
+    double eps_max;  // 1-D aliasing error at the image edge (its maximum); like eps an RMS over the sub-cell position
+    double eps_sup;  // ... for the WORST sub-cell position: the bound that holds for a single visibility (admissibility test)
 };
 
 const KernelRow *kernel_table(size_t *n);

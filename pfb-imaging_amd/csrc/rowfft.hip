@@ -160,77 +160,24 @@ struct PadTLoad {
     __device__ __forceinline__ double2 operator()(int v, int s) const { return finish(fetch(v, s), v, s); }
 };
 
-// L2 warm-up (round 3).  A row-FFT workgroup is the only one on its CU, and its time is (HBM time of its row at the share of
-// the bandwidth the workgroups in their I/O phase get) + (passes): the two do not overlap inside a CU, and over the chip they
-// ADD (a2b at C2: 2.8 GB at ~5 TB/s = 0.55 ms, + 0.65 ms of passes = the 1.2 ms measured).  Registers and LDS are full, so
-// the next row cannot be staged on chip; instead every workgroup, once its own requests are out, requests ONE dword per
-// 128-byte line of the row that the workgroup `ahead` positions later in dispatch order will transform -- the one that takes
-// this CU (and, block ids being dealt round robin, this XCD's L2) next -- and consumes the dwords after its passes.  The
-// next workgroup's requests then hit L2 / MALL while HBM streams under the passes.  ahead = CUs x workgroups per CU
-// (PFBHIP_RF_AHEAD overrides, 0 disables).
-struct RfTouch {
-    uint32_t v[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // (no arithmetic on these before consume(): it would wait for the data)
-    // lines [0, nlines) of `row` (128 bytes each), thread t of T takes lines t, t + T, ... into v[slot0 ...]; keep(l) = line wanted
-    template <int T, int NL, int SLOT0 = 0, class Keep>
-    __device__ __forceinline__ void row(const void *rowp, int nlines, int t, Keep &&keep)
-    {
-        static_assert(SLOT0 + NL <= 8, "RfTouch holds eight dwords per thread");
-        const char *p = static_cast<const char *>(rowp);
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int l = t + i * T;
-            if (l < nlines && keep(l)) v[SLOT0 + i] = *reinterpret_cast<const uint32_t *>(p + size_t(l) * 128);
-        }
-    }
-    __device__ __forceinline__ void consume() const
-    {
-        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-    }
-};
-static int rf_ahead(int wg_per_cu)
-{
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    const char *env = std::getenv("PFBHIP_RF_AHEAD");
-    return env != nullptr ? std::max(0, std::atoi(env)) : cus * wg_per_cu;
-}
-
+// (Round 3 tried an L2 warm-up here -- every workgroup, once its own requests were out, requested one dword per 128-byte line
+// of the row its CU would take next, with all twiddles requested up front so that no later wait drained those requests.
+// Measured on C2: first axis 2.17 -> 2.32 ms, fused second axis unchanged; removed.  DESIGN.md section 5.1.)
 // blockIdx.y = plane of the launch (astride / bstride elements apart): one launch for all planes of a pass leaves one
 // partially filled round of workgroups instead of one per plane (4896 rows on 256 CUs: 19.1 rounds each)
 template <class S>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_a2b(const double2 *tw, const double2 *A, double2 *B,
                                                                           const int *rowmap, int nrows, int nu, int ny, size_t apitch,
-                                                                          size_t astride, size_t bstride, const int4 *colruns, int ahead)
+                                                                          size_t astride, size_t bstride, const int4 *colruns)
 {
     extern __shared__ double rf_lds[];
     if (int(blockIdx.x) >= nrows) return;
     const int u = rowmap[blockIdx.x];
-    // the workgroup `ahead` later in dispatch order (x fastest): its row is warmed below
-    const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x + uint32_t(ahead);
-    const uint32_t nxb = lin % gridDim.x, nyb = lin / gridDim.x;
-    const bool warm = ahead > 0 && nyb < gridDim.y && int(nxb) < nrows;
-    const int u2 = warm ? rowmap[nxb] : u;
-    const double2 *nrow = A + size_t(warm ? nyb : blockIdx.y) * astride + size_t(u2) * apitch;
-    const int4 r2 = colruns[u2 >> 5];
     A += size_t(blockIdx.y) * astride;
     B += size_t(blockIdx.y) * bstride;
     RunLoad ld{A + size_t(u) * apitch, colruns[u >> 5]};
     CropTStore st{B, u, nu, ny, S::N, ny / 2};
-    RfTouch touch;
-    constexpr int NLINES = S::N / 8, NL = (NLINES + S::T - 1) / S::T;
-    const int tt = int(threadIdx.x);
-    auto hook = [&] {
-        if (warm)  // (column runs are whole 32-element tiles: a line lies inside a run or outside)
-            touch.template row<S::T, NL>(nrow, NLINES, tt, [&](int l) { return (8 * l >= r2.x && 8 * l < r2.y) || (8 * l >= r2.z && 8 * l < r2.w); });
-    };
-    if constexpr (S::WARM) rf_row<S>(tw, ld, st, true, rf_lds, hook);
-    else rf_row<S>(tw, ld, st, true, rf_lds);
-    touch.consume();
+    rf_row<S>(tw, ld, st, true, rf_lds);
 }
 
 // Row u of Bt (tpitch elements per row, written by the fused pad kernel with the transpose in ITS stores): contiguous loads.
@@ -246,35 +193,131 @@ struct PadRowLoad {
 template <class S, bool TR>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_rowfft_b2a(const double2 *tw, const double2 *B, double2 *A,
                                                                           const int *rowmap, int nrows, int nu, int ny, size_t apitch,
-                                                                          int tpitch, size_t astride, size_t bstride, const int4 *colruns,
-                                                                          int ahead)
+                                                                          int tpitch, size_t astride, size_t bstride, const int4 *colruns)
 {
     extern __shared__ double rf_lds[];
     if (int(blockIdx.x) >= nrows) return;
     const int u = rowmap[blockIdx.x];
-    const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x + uint32_t(ahead);
-    const uint32_t nxb = lin % gridDim.x, nyb = lin / gridDim.x;
-    const bool warm = TR && ahead > 0 && nyb < gridDim.y && int(nxb) < nrows;
-    const int u2 = warm ? rowmap[nxb] : u;
-    const double2 *nrow = B + size_t(warm ? nyb : blockIdx.y) * bstride + size_t(u2) * size_t(tpitch);  // (Bt row of the next workgroup)
     A += size_t(blockIdx.y) * astride;
     B += size_t(blockIdx.y) * bstride;
     RunStore st{A + size_t(u) * apitch, colruns[u >> 5]};
     if constexpr (TR) {
         PadRowLoad ld{B + size_t(u) * size_t(tpitch), ny, S::N, ny / 2};
-        RfTouch touch;
-        constexpr int NL = (S::N / 8 + S::T - 1) / S::T;  // (ny <= N lines at most)
-        const int tt = int(threadIdx.x), nlines = (ny + 7) / 8;
-        auto hook = [&] {
-            if (warm) touch.template row<S::T, NL>(nrow, nlines, tt, [](int) { return true; });
-        };
-        if constexpr (S::WARM) rf_row<S>(tw, ld, st, false, rf_lds, hook);
-        else rf_row<S>(tw, ld, st, false, rf_lds);
-        touch.consume();
+        rf_row<S>(tw, ld, st, false, rf_lds);
     } else {
         PadTLoad ld{B, u, nu, ny, S::N, ny / 2};
         rf_row<S>(tw, ld, st, false, rf_lds);
     }
+}
+
+// slots of the waiting half that fit behind the exchange buffer (the rest stay in registers); 0: no stash
+template <class S1>
+constexpr int rf_stash_slots()
+{
+    const int room = (160 * 1024 - S1::LDS_BYTES) / int(sizeof(double)) / S1::T;
+    return room >= S1::E - 2 ? (room < S1::E ? room : S1::E) : 0;
+}
+
+// Doubled shapes: the generic rf_row<RfShape2> keeps all 2 x 16 outputs (128 VGPRs) next to the waiting half and spills 200+
+// registers; here, as in the fused second-axis kernels, the even half's real parts are parked in LDS while the odd half is
+// transformed (STASH) and every output pair is stored as soon as it is combined.
+template <class S1, bool STASH, class Load, class Store>
+__device__ __forceinline__ void rf_row2(const double2 *__restrict__ tw, Load &ld, Store &st, bool inverse, double *rf_lds)
+{
+    double *stash = rf_lds + S1::LDS_BYTES / sizeof(double);
+    RfHalfLoad<Load, 0, 0> ld_e{ld};
+    RfHalfLoad<Load, 1, S1::NSLOT> ld_o{ld};
+    double er[S1::E], ei[S1::E], orr[S1::E], oi[S1::E];
+    int t;
+    rf_row_compute<S1>(tw, ld_e, inverse, rf_lds, t, er, ei);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NST = STASH ? rf_stash_slots<S1>() : 0;
+#pragma unroll
+    for (int e = 0; e < NST; ++e) stash[e * S1::T + t] = er[e];
+    rf_row_compute<S1, decltype(ld_o), 2>(tw, ld_o, inverse, rf_lds, t, orr, oi);
+    __builtin_amdgcn_sched_barrier(0);
+    rf_opaque(t);
+    const double2 *__restrict__ tw2 = tw + S1::N;
+#pragma unroll
+    for (int e = 0; e < S1::E; ++e) {
+        const int k1 = S1::out_pos(t, e);
+        const double2 w = tw2[k1];
+        const double ere = e < NST ? stash[e * S1::T + t] : er[e];
+        // (the inverse is the forward transform of the (im, re)-swapped row, swapped back on the way out: the combination
+        // below works in that swapped domain with the forward twiddle, like rf_row_compute's doubled branch)
+        const double tr = orr[e] * w.x - oi[e] * w.y, ti = orr[e] * w.y + oi[e] * w.x;
+        const double2 lo = make_double2(ere + tr, ei[e] + ti), hi = make_double2(ere - tr, ei[e] - ti);
+        st(k1, inverse ? make_double2(lo.y, lo.x) : lo);
+        st(k1 + S1::N, inverse ? make_double2(hi.y, hi.x) : hi);
+        // (four combination twiddles requested at a time: all 16 would cost 64 VGPRs.  Computing them as w^t w^(c T) with
+        // scalar-loaded w^(c T) was measured 5-10 % slower on C5: r03g vs r03f)
+        if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <class S1, bool STASH>
+__global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4) k_rowfft_a2b2(const double2 *tw, const double2 *A, double2 *B,
+                                                                                    const int *rowmap, int nrows, int nu, int ny,
+                                                                                    size_t apitch, size_t astride, size_t bstride,
+                                                                                    const int4 *colruns)
+{
+    extern __shared__ double rf_lds[];
+    if (int(blockIdx.x) >= nrows) return;
+    const int u = rowmap[blockIdx.x];
+    A += size_t(blockIdx.y) * astride;
+    B += size_t(blockIdx.y) * bstride;
+    RunLoad ld{A + size_t(u) * apitch, colruns[u >> 5]};
+    CropTStore st{B, u, nu, ny, 2 * S1::N, ny / 2};
+    rf_row2<S1, STASH>(tw, ld, st, true, rf_lds);
+}
+template <class S1, bool TR, bool STASH>
+__global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4) k_rowfft_b2a2(const double2 *tw, const double2 *B, double2 *A,
+                                                                                    const int *rowmap, int nrows, int nu, int ny,
+                                                                                    size_t apitch, int tpitch, size_t astride,
+                                                                                    size_t bstride, const int4 *colruns)
+{
+    extern __shared__ double rf_lds[];
+    if (int(blockIdx.x) >= nrows) return;
+    const int u = rowmap[blockIdx.x];
+    A += size_t(blockIdx.y) * astride;
+    B += size_t(blockIdx.y) * bstride;
+    RunStore st{A + size_t(u) * apitch, colruns[u >> 5]};
+    if constexpr (TR) {
+        PadRowLoad ld{B + size_t(u) * size_t(tpitch), ny, 2 * S1::N, ny / 2};
+        rf_row2<S1, STASH>(tw, ld, st, false, rf_lds);
+    } else {
+        PadTLoad ld{B, u, nu, ny, 2 * S1::N, ny / 2};
+        rf_row2<S1, STASH>(tw, ld, st, false, rf_lds);
+    }
+}
+template <class S1>
+static void launch_a2b2(const RowFFTPlan &pl, const double2 *A, double2 *B, const int *rowmap, int nrows, int nu, int ny,
+                        size_t apitch, int nplanes, size_t astride, size_t bstride, const int4 *colruns, hipStream_t stream)
+{
+    static bool attr = false;
+    constexpr bool STASH = rf_stash_slots<S1>() > 0;
+    rf_allow_lds(&k_rowfft_a2b2<S1, STASH>, &attr);
+    hipLaunchKernelGGL((k_rowfft_a2b2<S1, STASH>), dim3(uint32_t((nrows + 7) / 8 * 8), uint32_t(nplanes)), dim3(S1::T),
+                       size_t(S1::LDS_BYTES) + size_t(rf_stash_slots<S1>()) * S1::T * sizeof(double), stream, pl.twiddle, A, B, rowmap,
+                       nrows, nu, ny, apitch, astride, bstride, colruns);
+}
+template <class S1>
+static void launch_b2a2(const RowFFTPlan &pl, const double2 *B, double2 *A, const int *rowmap, int nrows, int nu, int ny,
+                        size_t apitch, int tpitch, int nplanes, size_t astride, size_t bstride, const int4 *colruns, hipStream_t stream)
+{
+    static bool attr = false, attr_t = false;
+    constexpr bool STASH = rf_stash_slots<S1>() > 0;
+    const dim3 grid(uint32_t((nrows + 7) / 8 * 8), uint32_t(nplanes));
+    const size_t lds = size_t(S1::LDS_BYTES) + size_t(rf_stash_slots<S1>()) * S1::T * sizeof(double);
+    if (tpitch > 0) {
+        rf_allow_lds(&k_rowfft_b2a2<S1, true, STASH>, &attr_t);
+        hipLaunchKernelGGL((k_rowfft_b2a2<S1, true, STASH>), grid, dim3(S1::T), lds, stream, pl.twiddle, B, A, rowmap, nrows, nu, ny,
+                           apitch, tpitch, astride, bstride, colruns);
+        return;
+    }
+    rf_allow_lds(&k_rowfft_b2a2<S1, false, STASH>, &attr);
+    hipLaunchKernelGGL((k_rowfft_b2a2<S1, false, STASH>), grid, dim3(S1::T), lds, stream, pl.twiddle, B, A, rowmap, nrows, nu, ny, apitch,
+                       0, astride, bstride, colruns);
 }
 
 template <class S>
@@ -285,7 +328,7 @@ static void launch_a2b(const RowFFTPlan &pl, const double2 *A, double2 *B, const
     rf_allow_lds(&k_rowfft_a2b<S>, &attr);
     // (grid.x a multiple of 8: a plane's workgroups then start on XCD 0 like the first plane's -- rowmap relies on it)
     hipLaunchKernelGGL((k_rowfft_a2b<S>), dim3(uint32_t((nrows + 7) / 8 * 8), uint32_t(nplanes)), dim3(S::T), size_t(S::LDS_BYTES),
-                       stream, pl.twiddle, A, B, rowmap, nrows, nu, ny, apitch, astride, bstride, colruns, rf_ahead(S::WG_PER_CU));
+                       stream, pl.twiddle, A, B, rowmap, nrows, nu, ny, apitch, astride, bstride, colruns);
 }
 template <class S>
 static void launch_b2a(const RowFFTPlan &pl, const double2 *B, double2 *A, const int *rowmap, int nrows, int nu, int ny,
@@ -296,22 +339,25 @@ static void launch_b2a(const RowFFTPlan &pl, const double2 *B, double2 *A, const
     if (tpitch > 0) {
         rf_allow_lds(&k_rowfft_b2a<S, true>, &attr_t);
         hipLaunchKernelGGL((k_rowfft_b2a<S, true>), grid, dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A, rowmap, nrows,
-                           nu, ny, apitch, tpitch, astride, bstride, colruns, rf_ahead(S::WG_PER_CU));
+                           nu, ny, apitch, tpitch, astride, bstride, colruns);
         return;
     }
     rf_allow_lds(&k_rowfft_b2a<S, false>, &attr);
     hipLaunchKernelGGL((k_rowfft_b2a<S, false>), grid, dim3(S::T), size_t(S::LDS_BYTES), stream, pl.twiddle, B, A, rowmap, nrows, nu,
-                       ny, apitch, 0, astride, bstride, colruns, 0);
+                       ny, apitch, 0, astride, bstride, colruns);
 }
 
 void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, const int *rowmap_dev, int nrows, int nu, int ny,
                 size_t apitch, int nplanes, size_t astride, size_t bstride, const int4 *colruns, hipStream_t stream)
 {
-    PFB_REQUIRE(!pl.doubled, "transposing row FFT: doubled shapes are not supported");
     switch (pl.N) {
 #define RF_X(L, K)                                                                       \
     case (L << K): launch_a2b<RfShape<L, K>>(pl, A_dev, B_dev, rowmap_dev, nrows, nu, ny, apitch, nplanes, astride, bstride, colruns, stream); break;
         RF_FOR_SHAPES(RF_X)
+#undef RF_X
+#define RF_X(L, K)                                                                       \
+    case 2 * (L << K): launch_a2b2<RfShape<L, K, false>>(pl, A_dev, B_dev, rowmap_dev, nrows, nu, ny, apitch, nplanes, astride, bstride, colruns, stream); break;
+        RF_FOR_SHAPES2(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);
     }
@@ -321,11 +367,14 @@ void rowfft_a2b(const RowFFTPlan &pl, const double2 *A_dev, double2 *B_dev, cons
 void rowfft_b2a(const RowFFTPlan &pl, const double2 *B_dev, double2 *A_dev, const int *rowmap_dev, int nrows, int nu, int ny,
                 size_t apitch, int tpitch, int nplanes, size_t astride, size_t bstride, const int4 *colruns, hipStream_t stream)
 {
-    PFB_REQUIRE(!pl.doubled, "transposing row FFT: doubled shapes are not supported");
     switch (pl.N) {
 #define RF_X(L, K)                                                                       \
     case (L << K): launch_b2a<RfShape<L, K>>(pl, B_dev, A_dev, rowmap_dev, nrows, nu, ny, apitch, tpitch, nplanes, astride, bstride, colruns, stream); break;
         RF_FOR_SHAPES(RF_X)
+#undef RF_X
+#define RF_X(L, K)                                                                       \
+    case 2 * (L << K): launch_b2a2<RfShape<L, K, false>>(pl, B_dev, A_dev, rowmap_dev, nrows, nu, ny, apitch, tpitch, nplanes, astride, bstride, colruns, stream); break;
+        RF_FOR_SHAPES2(RF_X)
 #undef RF_X
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", pl.N);
     }
@@ -360,7 +409,7 @@ struct OccLoad {
 template <class S, bool SC>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(const double2 *tw, FusedGeom g, const uint8_t *occ,
                                                           const double2 *B, size_t bstride, FusedPlanes planes,
-                                                          int do_w, int first, int lds_row, double *accT, FusedFinal fin, int ahead)
+                                                          int do_w, int first, int lds_row, double *accT, FusedFinal fin)
 {
     extern __shared__ double rf_lds[];
     double *acc = rf_lds + S::LDS_BYTES / sizeof(double);
@@ -368,39 +417,11 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
     double *arow = accT + size_t(y) * g.nx;
     uint64_t mask = 0;
     rf_for_each_load<S>(int(threadIdx.x), [&](int u, int slot) { mask |= (occ[u >> 5] ? 1ull : 0ull) << slot; });
-    // L2 warm-up (see RfTouch): during plane k the row of plane k + 1; during the last plane the first row of the workgroup
-    // that takes this CU next (image row y + ahead) and, when this launch finalizes, that row of corr / beam / x
-    constexpr int NLB = (S::N / 8 + S::T - 1) / S::T;
-    const int tt = int(threadIdx.x);
-    uint32_t wocc = 0;  // bit i: line tt + i T of a B row lies in an occupied 32-column block
-#pragma unroll
-    for (int i = 0; i < NLB; ++i)
-        if (tt + i * S::T < S::N / 8) wocc |= (occ[(tt + i * S::T) >> 2] ? 1u : 0u) << i;
-    const int y2 = (ahead > 0 && y + ahead < g.ny) ? y + ahead : -1;
     for (int k = 0; k < planes.kp; ++k) {
         OccLoad ld{B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch), mask};
         double re[S::E], im[S::E];
         int t;
-        RfTouch touch;
-        auto hook = [&] {
-            const bool lastk = k + 1 == planes.kp;
-            if (ahead > 0 && (!lastk || y2 >= 0)) {
-                const double2 *nrow = lastk ? B + size_t(y2) * size_t(g.bpitch) : B + size_t(k + 1) * bstride + size_t(y) * size_t(g.bpitch);
-                touch.template row<S::T, NLB>(nrow, S::N / 8, tt, [&](int l) { return ((wocc >> ((l - tt) / S::T)) & 1u) != 0; });
-                if (lastk && fin.corr != nullptr) {
-                    constexpr int NLI = 8 - NLB < 3 ? 8 - NLB : 3;  // lines per thread over the three image rows (nx / 16 lines each)
-                    const size_t ro2 = size_t(y2) * size_t(g.nx);
-                    const int nli = g.nx / 16;
-                    touch.template row<S::T, NLI, NLB>(fin.corr + ro2, 3 * nli, tt, [&](int l) { return l < nli; });
-                    if (fin.beam != nullptr)
-                        touch.template row<S::T, NLI, NLB>(fin.beam + ro2 - size_t(nli) * 16, 3 * nli, tt, [&](int l) { return l >= nli && l < 2 * nli; });
-                    if (fin.x != nullptr)
-                        touch.template row<S::T, NLI, NLB>(fin.x + ro2 - size_t(2 * nli) * 16, 3 * nli, tt, [&](int l) { return l >= 2 * nli; });
-                }
-            }
-        };
-        if constexpr (S::WARM) rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im, hook);
-        else rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
+        rf_row_compute<S>(tw, ld, true, rf_lds, t, re, im);
         rf_opaque(t);
         const double wk = planes.w[k];
         double cc[FUSED_SCMAX], ss[FUSED_SCMAX];  // SC: this plane's composite screen polynomials
@@ -445,7 +466,6 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
                 }
                 if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the number of sincos chains in flight
             }
-            touch.consume();
             continue;
         }
         // rows the groups request from (always valid memory: absent arrays alias the accumulator row and are dropped)
@@ -499,7 +519,6 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
             const int ix = fg_ix(g, S::out_pos(t, e));
             if (ix >= 0) orow[ix] = re[e];
         }
-        touch.consume();
     }
 }
 
@@ -539,21 +558,17 @@ using PadLoad = PadLoadT<false, false>;
 template <class S, bool SC>
 __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const double2 *tw, FusedGeom g, const uint8_t *occ,
                                                          const double *dcT, FusedPrep prep, FusedPlanes planes, int do_w,
-                                                         int lds_row, double2 *B, size_t bstride, int ahead)
+                                                         int lds_row, double2 *B, size_t bstride)
 {
     extern __shared__ double rf_lds[];
     double *lrow = rf_lds + S::LDS_BYTES / sizeof(double);
-    // transposed stores (below): the 8 rows y whose 16-byte pieces make up one 128-byte line of Bt go to 8 workgroups of
-    // ONE XCD (block ids equal mod 8) inside the same 64 block ids, so that the line leaves that XCD's L2 whole
-    auto row_of = [&](int b) {
-        if (g.tpitch > 0 && b < (g.ny & ~63)) {
-            const int r = b & 63;
-            return (b & ~63) + (r & 7) * 8 + (r >> 3);
-        }
-        return b;
-    };
-    const int y = row_of(int(blockIdx.x));
-    const int y2 = (ahead > 0 && int(blockIdx.x) + ahead < g.ny) ? row_of(int(blockIdx.x) + ahead) : -1;  // (L2 warm-up, see RfTouch)
+    int y = blockIdx.x;
+    if (g.tpitch > 0 && y < (g.ny & ~63)) {
+        // transposed stores (below): the 8 rows y whose 16-byte pieces make up one 128-byte line of Bt go to 8 workgroups of
+        // ONE XCD (block ids equal mod 8) inside the same 64 block ids, so that the line leaves that XCD's L2 whole
+        const int r = y & 63;
+        y = (y & ~63) + (r & 7) * 8 + (r >> 3);
+    }
     uint32_t omask = 0;  // occupancy of the thread's output columns
 #pragma unroll
     for (int e = 0; e < S::E; ++e) omask |= (occ[S::out_pos(int(threadIdx.x), e) >> 5] ? 1u : 0u) << e;
@@ -582,7 +597,10 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
                 if (slot / NH == h) {
                     const int ix = fg_ix(g, u);
                     double v = vx[slot % NH];
-                    if (raw) v *= has_beam ? vc[slot % NH] * vb[slot % NH] : vc[slot % NH];
+                    if (raw) {  // (x * corr) * beam: the rounding order of k_prepare_img, which the read-modify-write form uses
+                        v *= vc[slot % NH];
+                        if (has_beam) v *= vb[slot % NH];
+                    }
                     if (ix >= 0) lrow[ix] = v;
                 }
             });
@@ -601,22 +619,7 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
             PadLoadT<SC, LROW> ld{LROW ? lrow : dcT + ro, g, cc, ss, y, do_w, planes.w[k]};
             double re[S::E], im[S::E];
             int t;
-            RfTouch touch;
-            auto hook = [&] {
-                if (k == 0 && y2 >= 0) {  // the image rows the next workgroup's pre-pass (or plane loop) reads: nx / 16 lines each
-                    const size_t ro2 = size_t(y2) * size_t(g.nx);
-                    const int nli = g.nx / 16, tt = int(threadIdx.x);
-                    const bool raw = prep.x != nullptr;
-                    touch.template row<S::T, 3, 0>((raw ? prep.x : dcT) + ro2, 3 * nli, tt, [&](int l) { return l < nli; });
-                    if (raw) {
-                        touch.template row<S::T, 3, 0>(prep.corr + ro2 - size_t(nli) * 16, 3 * nli, tt, [&](int l) { return l >= nli && l < 2 * nli; });
-                        if (prep.beam != nullptr)
-                            touch.template row<S::T, 3, 0>(prep.beam + ro2 - size_t(2 * nli) * 16, 3 * nli, tt, [&](int l) { return l >= 2 * nli; });
-                    }
-                }
-            };
-            if constexpr (S::WARM) rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im, hook);
-            else rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
+            rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
             rf_opaque(t);
             __builtin_amdgcn_sched_barrier(0);
             if (g.tpitch > 0) {  // Bt[u][y]: the first-axis transform of row u then reads contiguously (k_rowfft_b2a<S, true>)
@@ -630,7 +633,6 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
                 for (int e = 0; e < S::E; ++e)
                     if ((omask >> e) & 1u) brow[S::out_pos(t, e)] = make_double2(re[e], im[e]);
             }
-            touch.consume();
         }
     };
     if (lds_row) planes_loop(std::true_type{});
@@ -797,12 +799,19 @@ struct OccLoad2 {
     __device__ __forceinline__ double2 operator()(int pos, int slot) const { return finish(fetch(pos, slot), pos, slot); }
 };
 
-template <class S1>
+// STASH (round 3; shapes with 2 N1 doubles of LDS next to each other: 20480 points): the half transform that waits is parked in
+// LDS, not in registers -- er behind the exchange buffer while the odd half is transformed, ei in the (then idle) exchange
+// buffer during the epilogue; thread-private cells, one barrier per plane.  With both halves in registers next to a running
+// transform the kernel spilled ~100 VGPRs and lost to the unfused path (36.8 vs 35.6 ms per 4 planes at C5's size).  The
+// epilogue requests the running sum / correction / beam / x of FOUR outputs at a time from clamped addresses, one group ahead
+// (see k_fused_fft_crop), and stores after the last group.
+template <class S1, bool STASH>
 __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
     k_fused_fft_crop2(const double2 *tw, FusedGeom g, const uint8_t *occ, const double2 *B, size_t bstride, FusedPlanes planes,
                       int do_w, int first, double *accT, FusedFinal fin)
 {
     extern __shared__ double rf_lds[];
+    double *stash = rf_lds + S1::LDS_BYTES / sizeof(double);  // STASH: S1::N doubles behind the exchange buffer
     const int y = blockIdx.x;
     double *arow = accT + size_t(y) * g.nx;
     // samples 2 pos and 2 pos + 1 lie in the same 32-column block: one occupancy mask serves both halves
@@ -816,46 +825,100 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
         int t;
         rf_row_compute<S1>(tw, ld_e, true, rf_lds, t, er, ei);
         __builtin_amdgcn_sched_barrier(0);
-        rf_row_compute<S1>(tw, ld_o, true, rf_lds, t, orr, oi);
+        constexpr int NST = STASH ? rf_stash_slots<S1>() : 0;
+#pragma unroll
+        for (int e = 0; e < NST; ++e) stash[e * S1::T + t] = er[e];
+        rf_row_compute<S1, decltype(ld_o), 2>(tw, ld_o, true, rf_lds, t, orr, oi);
         __builtin_amdgcn_sched_barrier(0);
         rf_opaque(t);
+        if constexpr (STASH) {  // (behind the transform's last barrier nobody reads the exchange buffer any more)
+#pragma unroll
+            for (int e = 0; e < S1::E; ++e) rf_lds[e * S1::T + t] = ei[e];
+        }
         const double wk = planes.w[k];
         const bool last = k == planes.kp - 1;
         const bool add_img = !(first && k == 0);
         const bool finalize = last && fin.corr != nullptr;
+        const size_t ro = size_t(y) * size_t(g.nx);
+        const bool has_beam = finalize && fin.beam != nullptr, has_x = finalize && fin.x != nullptr;
+        const double *crow = finalize ? fin.corr + ro : arow;
+        const double *brow = has_beam ? fin.beam + ro : crow;
+        const double *xrow = has_x ? fin.x + ro : crow;
+        // group = one slot e = two outputs (k1 and k1 + N1)
+        constexpr int NG = S1::E;
+        double qi[2][2], qc[2][2], qb[2][2], qx[2][2];
+        auto request = [&](int e0, int buf) {
 #pragma unroll
-        for (int e = 0; e < S1::E; ++e) {
-            const int k1 = S1::out_pos(t, e);
-            const double2 w = tw2[k1];
-            const double tr = orr[e] * w.x - oi[e] * w.y, ti = orr[e] * w.y + oi[e] * w.x;
+            for (int j = 0; j < 2; ++j) {
+                const int ixc = max(fg_ix(g, S1::out_pos(t, e0) + j * S1::N), 0);
+                qi[buf][j] = arow[ixc];
+                qc[buf][j] = crow[ixc];
+                qb[buf][j] = brow[ixc];
+                qx[buf][j] = xrow[ixc];
+            }
+        };
+        request(0, 0);
+        // results wait in the LDS cells their slot's parked values leave behind (STASH), else in registers, and are stored
+        // after the last group
+        double res[STASH ? 2 * (S1::E - NST) + 1 : 2 * S1::E];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const double vre = h ? er[e] - tr : er[e] + tr, vim = h ? ei[e] - ti : ei[e] + ti;
-                const int ix = fg_ix(g, k1 + h * S1::N);
-                if (ix >= 0) {
-                    double r = vim;  // inverse transform: value = (im, re)
-                    if (do_w) {
-                        double ph = wk * fg_t(g, ix, y);
-                        ph -= rint(ph);
-                        double sn, cs;
-                        fg_sincos2pi(ph, sn, cs);
-                        r = vim * cs + vre * sn;
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) request(gq + 1, (gq + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int e = gq;
+                const int k1 = S1::out_pos(t, e);
+                const double2 w = tw2[k1];
+                const double ere = e < NST ? stash[e * S1::T + t] : er[e], eim = STASH ? rf_lds[e * S1::T + t] : ei[e];
+                const double tr = orr[e] * w.x - oi[e] * w.y, ti = orr[e] * w.y + oi[e] * w.x;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double vre = h ? ere - tr : ere + tr, vim = h ? eim - ti : eim + ti;
+                    const int ix = fg_ix(g, k1 + h * S1::N);
+                    const int j = h;
+                    double v = 0.0;
+                    if (ix >= 0) {
+                        double r = vim;  // inverse transform: value = (im, re)
+                        if (do_w) {
+                            double ph = wk * fg_t(g, ix, y);
+                            ph -= rint(ph);
+                            double sn, cs;
+                            fg_sincos2pi(ph, sn, cs);
+                            r = vim * cs + vre * sn;
+                        }
+                        if (add_img) r += qi[gq & 1][j];
+                        if (finalize) {
+                            const double c = has_beam ? qc[gq & 1][j] * qb[gq & 1][j] : qc[gq & 1][j];
+                            v = r * c * fin.scale;
+                            if (has_x) v += fin.eta * qx[gq & 1][j];
+                        } else {
+                            v = r;
+                        }
                     }
-                    if (add_img) r += arow[ix];
-                    if (finalize) {
-                        const size_t o = size_t(y) * size_t(g.nx) + size_t(ix);
-                        double v = r * fin.corr[o];
-                        if (fin.beam != nullptr) v *= fin.beam[o];
-                        v *= fin.scale;
-                        if (fin.x != nullptr) v += fin.eta * fin.x[o];
-                        fin.out[o] = v;
+                    if constexpr (STASH) {
+                        if (h == 1) rf_lds[e * S1::T + t] = v;
+                        else if (e < NST) stash[e * S1::T + t] = v;
+                        else res[2 * (e - NST)] = v;
                     } else {
-                        arow[ix] = r;
+                        res[2 * e + h] = v;
                     }
                 }
             }
-            if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the number of sincos chains in flight
+            __builtin_amdgcn_sched_barrier(0);
         }
+        double *orow = finalize ? fin.out + ro : arow;
+#pragma unroll
+        for (int e = 0; e < S1::E; ++e) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ix = fg_ix(g, S1::out_pos(t, e) + h * S1::N);
+                double v;
+                if constexpr (STASH) v = h == 1 ? rf_lds[e * S1::T + t] : (e < NST ? stash[e * S1::T + t] : res[2 * (e - NST)]);
+                else v = res[2 * e + h];
+                if (ix >= 0) orow[ix] = v;
+            }
+        }
+        if constexpr (STASH) rf_barrier();  // the next plane's transform writes the exchange buffer (the parked ei of slow waves)
     }
 }
 
@@ -867,13 +930,18 @@ struct PadLoad2 {
     __device__ __forceinline__ double2 operator()(int pos, int slot) const { return base(2 * pos + par, slot); }
 };
 
-template <class S1>
+template <class S1, bool STASH>
 __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
     k_fused_pad_fft2(const double2 *tw, FusedGeom g, const uint8_t *occ, const double *dcT, FusedPrep prep, FusedPlanes planes,
                      int do_w, double2 *B, size_t bstride)
 {
     extern __shared__ double rf_lds[];
-    const int y = blockIdx.x;
+    double *stash = rf_lds + S1::LDS_BYTES / sizeof(double);  // STASH: the even half's real parts wait here (see k_fused_fft_crop2)
+    int y = blockIdx.x;
+    if (g.tpitch > 0 && y < (g.ny & ~63)) {  // transposed stores: the 8 rows of a 128-byte line of Bt on one XCD (see k_fused_pad_fft)
+        const int r = y & 63;
+        y = (y & ~63) + (r & 7) * 8 + (r >> 3);
+    }
     uint32_t omask = 0;  // bit e: column out_pos(e) occupied, bit 16 + e: column N1 + out_pos(e)
 #pragma unroll
     for (int e = 0; e < S1::E; ++e) {
@@ -891,17 +959,24 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
         int t;
         rf_row_compute<S1>(tw, ld_e, false, rf_lds, t, er, ei);
         __builtin_amdgcn_sched_barrier(0);
-        rf_row_compute<S1>(tw, ld_o, false, rf_lds, t, orr, oi);
+        constexpr int NST = STASH ? rf_stash_slots<S1>() : 0;
+#pragma unroll
+        for (int e = 0; e < NST; ++e) stash[e * S1::T + t] = er[e];
+        rf_row_compute<S1, decltype(ld_o), 2>(tw, ld_o, false, rf_lds, t, orr, oi);
         __builtin_amdgcn_sched_barrier(0);
         rf_opaque(t);
-        double2 *brow = B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch);
+        // B[y][u], or Bt[u][y] for the transposing first axis (g.tpitch > 0)
+        double2 *bbase = B + size_t(k) * bstride + (g.tpitch > 0 ? size_t(y) : size_t(y) * size_t(g.bpitch));
+        const size_t ustep = g.tpitch > 0 ? size_t(g.tpitch) : size_t(1);
 #pragma unroll
         for (int e = 0; e < S1::E; ++e) {
             const int k1 = S1::out_pos(t, e);
             const double2 w = tw2[k1];
+            const double ere = e < NST ? stash[e * S1::T + t] : er[e];
             const double tr = orr[e] * w.x - oi[e] * w.y, ti = orr[e] * w.y + oi[e] * w.x;
-            if ((omask >> e) & 1u) brow[k1] = make_double2(er[e] + tr, ei[e] + ti);
-            if ((omask >> (16 + e)) & 1u) brow[k1 + S1::N] = make_double2(er[e] - tr, ei[e] - ti);
+            if ((omask >> e) & 1u) bbase[size_t(k1) * ustep] = make_double2(ere + tr, ei[e] + ti);
+            if ((omask >> (16 + e)) & 1u) bbase[size_t(k1 + S1::N) * ustep] = make_double2(ere - tr, ei[e] - ti);
+            if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (at most four combination twiddles in flight)
         }
     }
 }
@@ -912,9 +987,11 @@ static void launch_crop2(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t
                          hipStream_t stream)
 {
     static bool attr = false;
-    rf_allow_lds(&k_fused_fft_crop2<S1>, &attr);
-    hipLaunchKernelGGL(k_fused_fft_crop2<S1>, dim3(uint32_t(g.ny)), dim3(S1::T), size_t(S1::LDS_BYTES), stream, pl.twiddle, g,
-                       occ_dev, B_dev, bstride, planes, do_w, first ? 1 : 0, accT_dev, fin);
+    constexpr bool STASH = rf_stash_slots<S1>() > 0;
+    rf_allow_lds(&k_fused_fft_crop2<S1, STASH>, &attr);
+    hipLaunchKernelGGL((k_fused_fft_crop2<S1, STASH>), dim3(uint32_t(g.ny)), dim3(S1::T),
+                       size_t(S1::LDS_BYTES) + size_t(rf_stash_slots<S1>()) * S1::T * sizeof(double), stream,
+                       pl.twiddle, g, occ_dev, B_dev, bstride, planes, do_w, first ? 1 : 0, accT_dev, fin);
 }
 template <class S1>
 static void launch_pad2(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev,
@@ -923,9 +1000,11 @@ static void launch_pad2(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t 
 {
     static bool attr = false;
     PFB_REQUIRE(prep.x == nullptr, "fused pad kernel of the doubled shapes needs a prepared image (fused_pad_takes_prep)");
-    rf_allow_lds(&k_fused_pad_fft2<S1>, &attr);
-    hipLaunchKernelGGL(k_fused_pad_fft2<S1>, dim3(uint32_t(g.ny)), dim3(S1::T), size_t(S1::LDS_BYTES), stream, pl.twiddle, g,
-                       occ_dev, dcT_dev, prep, planes, do_w, B_dev, bstride);
+    constexpr bool STASH = rf_stash_slots<S1>() > 0;
+    rf_allow_lds(&k_fused_pad_fft2<S1, STASH>, &attr);
+    hipLaunchKernelGGL((k_fused_pad_fft2<S1, STASH>), dim3(uint32_t(g.ny)), dim3(S1::T),
+                       size_t(S1::LDS_BYTES) + size_t(rf_stash_slots<S1>()) * S1::T * sizeof(double), stream,
+                       pl.twiddle, g, occ_dev, dcT_dev, prep, planes, do_w, B_dev, bstride);
 }
 
 // The fused kernels transpose one component at a time (N doubles of LDS), which leaves room for the
@@ -949,12 +1028,12 @@ static void launch_crop(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t 
     if (planes.nsc > 0 && do_w) {
         rf_allow_lds(&k_fused_fft_crop<S, true>, &attr_sc);
         hipLaunchKernelGGL((k_fused_fft_crop<S, true>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
-                           bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin, rf_ahead(S::WG_PER_CU));
+                           bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin);
         return;
     }
     rf_allow_lds(&k_fused_fft_crop<S, false>, &attr);
     hipLaunchKernelGGL((k_fused_fft_crop<S, false>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
-                       bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin, rf_ahead(S::WG_PER_CU));
+                       bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin);
 }
 
 template <class S>
@@ -969,12 +1048,12 @@ static void launch_pad(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *
     if (planes.nsc > 0 && do_w) {
         rf_allow_lds(&k_fused_pad_fft<S, true>, &attr_sc);
         hipLaunchKernelGGL((k_fused_pad_fft<S, true>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
-                           prep, planes, do_w, row ? 1 : 0, B_dev, bstride, rf_ahead(S::WG_PER_CU));
+                           prep, planes, do_w, row ? 1 : 0, B_dev, bstride);
         return;
     }
     rf_allow_lds(&k_fused_pad_fft<S, false>, &attr);
     hipLaunchKernelGGL((k_fused_pad_fft<S, false>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
-                       prep, planes, do_w, row ? 1 : 0, B_dev, bstride, rf_ahead(S::WG_PER_CU));
+                       prep, planes, do_w, row ? 1 : 0, B_dev, bstride);
 }
 
 void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double2 *B_dev, size_t bstride,
@@ -996,6 +1075,18 @@ void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev,
         default: PFB_REQUIRE(false, "row length %d is not supported by the hand-written FFT", f.pl.N);
     }
     PFB_HIP(hipGetLastError());
+}
+
+bool fused_doubled_stashes(const RowFFT &f)
+{
+    if (!f.ok || !f.pl.doubled) return false;
+    switch (f.pl.N) {
+#define RF_X(L, K) \
+    case 2 * (L << K): return rf_stash_slots<RfShape<L, K, false>>() > 0;
+        RF_FOR_SHAPES2(RF_X)
+#undef RF_X
+        default: return false;
+    }
 }
 
 bool fused_pad_takes_prep(const RowFFT &f, const FusedGeom &g)

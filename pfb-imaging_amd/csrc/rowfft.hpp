@@ -481,12 +481,8 @@ __device__ __forceinline__ double2 rf_finish(Load &ld, const typename rf_raw_typ
 // straight from the load functor, outputs written straight into the LDS transpose.
 // NB: butterflies whose requests are in flight together (two-step functors; RfShape::LOAD_BATCH: all of them where the
 // register budget allows, fewer in the 1024-thread shapes)
-struct RfNoHook {
-    __device__ __forceinline__ void operator()() const {}
-};
-template <int M, int E, bool DUAL, bool SWZ, int T, int N, int NL, int NB, class Load, class Hook = RfNoHook>
-__device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], int t, Load &ld, bool inverse, double *lds,
-                                             Hook &&after_requests = Hook{})
+template <int M, int E, bool DUAL, bool SWZ, int T, int N, int NL, int NB, class Load>
+__device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], int t, Load &ld, bool inverse, double *lds)
 {
     constexpr int IT = (E + M - 1) / M;
     constexpr bool PRE = rf_load_from_lds<Load>::value;
@@ -509,7 +505,6 @@ __device__ __forceinline__ void rf_first_odd(double (&re)[E], double (&im)[E], i
         for (int i = 0; i < BATCH; ++i) request(i);
         if constexpr (PRE) rf_barrier();
     }
-    after_requests();  // (the caller's L2 warm-up of the NEXT row: behind this row's requests in the in-order vmcnt queue)
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         if constexpr (BULK && BATCH < IT) {
@@ -611,8 +606,6 @@ struct RfShape {
     // leading odd pass: butterflies whose requests are in flight together (rf_first_odd): all of them at >= 168 VGPRs,
     // about 14 complex words' worth at the 128 of a 1024-thread workgroup
     static constexpr int LOAD_BATCH = WAVES_PER_SIMD <= 3 ? 64 : (LEAD_ >= 14 ? 1 : 14 / (LEAD_ > 1 ? LEAD_ : 1));
-    // L2 warm-up of the next row (kernels of rowfft.hip; costs the early twiddles' registers): not at the 128-VGPR budget
-    static constexpr bool WARM = WAVES_PER_SIMD <= 3;
     // position of the value left in slot e after the last pass
     static __device__ __forceinline__ int out_pos(int t, int e) { return t + rf_last_slot(RLAST, E, e) * T; }
 };
@@ -632,6 +625,7 @@ struct RfShape2 {
     static constexpr int LDS_BYTES = S1::LDS_BYTES;
     static constexpr int WG_PER_CU = 1;
     static constexpr int WAVES_PER_SIMD = ((T + 63) / 64 + 3) / 4;
+    static constexpr int LOAD_BATCH = 2;  // (of each half transform)
     static __device__ __forceinline__ int out_pos(int t, int e)
     {
         return e < S1::E ? S1::out_pos(t, e) : S1::N + S1::out_pos(t, e - S1::E);
@@ -679,56 +673,23 @@ struct RfHalfLoad<Load, PAR, SLOT0, true> {
     __device__ __forceinline__ double2 operator()(int pos, int slot) const { return ld(2 * pos + PAR, slot + SLOT0); }
 };
 
-// Every pass's twiddles of a thread, requested before anything else (rf_row_compute with a hook): the hook's requests then
-// sit BEHIND them in the in-order vmcnt queue and no later wait of the transform has to drain them.
-template <class S>
-struct RfTw {
-    double2 w[S::NP][S::E / 4];
-};
-template <class S, int P, int NS>
-__device__ __forceinline__ void rf_tw_load(RfTw<S> &tws, int t, const double2 *__restrict__ tw)
-{
-    constexpr int R = rf_radix(S::K, P);
-    if constexpr (NS > 1) {
-        double2 tmp[S::E / R];
-        rf_load_twiddles<R, S::E>(tmp, t, S::T, S::N, NS, tw);
-#pragma unroll
-        for (int i = 0; i < S::E / R; ++i) tws.w[P][i] = tmp[i];
-    }
-    if constexpr (P + 1 < S::NP) rf_tw_load<S, P + 1, NS * R>(tws, t, tw);
-}
-template <class S, int P, int NS>
-__device__ __forceinline__ void rf_passes_pre(double (&re)[S::E], double (&im)[S::E], int t, double *lds, const RfTw<S> &tws)
-{
-    constexpr int R = rf_radix(S::K, P);
-    double2 w1[S::E / R];
-#pragma unroll
-    for (int i = 0; i < S::E / R; ++i) w1[i] = tws.w[P][i];
-    rf_butterflies<R, S::E>(re, im, NS > 1, w1);
-    if constexpr (P + 1 < S::NP) {
-        rf_transpose<R, S::E, S::DUAL, S::SWZ, S::T, S::N, NS, S::xpad(R, NS), S::NL>(re, im, t, lds);
-        rf_passes_pre<S, P + 1, NS * R>(re, im, t, lds, tws);
-    }
-}
-
 // load -> passes; on return slot e holds the transform at position S::out_pos(t, e) as
 // (re[e], im[e]) for the forward transform and as (im[e], re[e]) for the (unnormalised) inverse.
-// `after_requests` (plain shapes only): called once the row's own requests are out -- where a kernel warms the L2 with
-// the row its CU will take next; all twiddles are then requested up front (RfTw).
-template <class S, class Load, class Hook = RfNoHook>
+// NB: butterflies of the leading odd pass whose requests are in flight together (default: the shape's LOAD_BATCH; the doubled
+// kernels, which hold half a transform next to the running one, ask for fewer)
+template <class S, class Load, int NB = S::LOAD_BATCH>
 __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, Load &ld, bool inverse, double *lds,
-                                               int &t_out, double (&re)[S::E], double (&im)[S::E], Hook &&after_requests = Hook{})
+                                               int &t_out, double (&re)[S::E], double (&im)[S::E])
 {
-    constexpr bool HOOKED = !std::is_same<std::decay_t<Hook>, RfNoHook>::value;
     if constexpr (S::DOUBLED) {
         using S1 = typename S::S1;
         double er[S1::E], ei[S1::E], orr[S1::E], oi[S1::E];
         RfHalfLoad<Load, 0, 0> ld_even{ld};
         RfHalfLoad<Load, 1, S1::NSLOT> ld_odd{ld};
         int t;
-        rf_row_compute<S1>(tw, ld_even, inverse, lds, t, er, ei);
+        rf_row_compute<S1, decltype(ld_even), S::LOAD_BATCH>(tw, ld_even, inverse, lds, t, er, ei);
         __builtin_amdgcn_sched_barrier(0);
-        rf_row_compute<S1>(tw, ld_odd, inverse, lds, t, orr, oi);  // er / ei wait in registers or scratch
+        rf_row_compute<S1, decltype(ld_odd), S::LOAD_BATCH>(tw, ld_odd, inverse, lds, t, orr, oi);  // er / ei wait in registers or scratch
         __builtin_amdgcn_sched_barrier(0);
         rf_opaque(t);
         const double2 *__restrict__ tw2 = tw + S1::N;  // exp(-2 pi i k / N), k < N1
@@ -751,16 +712,13 @@ __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, L
     t_out = t;
     constexpr int R0 = rf_radix(S::K, 0);
     double2 w0[S::E / R0] = {};
-    RfTw<S> tws;
-    if constexpr (HOOKED) rf_tw_load<S, 0, S::LEAD>(tws, t, tw);
     if constexpr (S::LEAD > 1) {
-        if constexpr (!HOOKED) rf_load_twiddles<R0, S::E>(w0, t, S::T, S::N, S::LEAD, tw);
-        rf_first_odd<S::LEAD, S::E, S::DUAL, S::SWZ, S::T, S::N, S::NL, S::LOAD_BATCH>(re, im, t, ld, inverse, lds, after_requests);
+        rf_load_twiddles<R0, S::E>(w0, t, S::T, S::N, S::LEAD, tw);
+        rf_first_odd<S::LEAD, S::E, S::DUAL, S::SWZ, S::T, S::N, S::NL, NB>(re, im, t, ld, inverse, lds);
     } else if constexpr (rf_has_fetch<Load>::value) {
         typename rf_raw_type<Load>::type raw[S::E];
 #pragma unroll
         for (int e = 0; e < S::E; ++e) raw[e] = ld.fetch(t + e * S::T, e);
-        after_requests();
 #pragma unroll
         for (int e = 0; e < S::E; ++e) {
             const double2 x = ld.finish(raw[e], t + e * S::T, e);
@@ -775,8 +733,7 @@ __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, L
             im[e] = inverse ? x.x : x.y;
         }
     }
-    if constexpr (HOOKED) rf_passes_pre<S, 0, S::LEAD>(re, im, t, lds, tws);
-    else rf_passes<S, 0, S::LEAD>(re, im, t, tw, lds, w0);
+    rf_passes<S, 0, S::LEAD>(re, im, t, tw, lds, w0);
     }
 }
 
@@ -806,13 +763,12 @@ __device__ __forceinline__ void rf_for_each_load(int t, F &&f)
 }
 
 // The whole row: load -> passes -> store.
-template <class S, class Load, class Store, class Hook = RfNoHook>
-__device__ __forceinline__ void rf_row(const double2 *__restrict__ tw, Load &ld, Store &st, bool inverse, double *lds,
-                                       Hook &&after_requests = Hook{})
+template <class S, class Load, class Store>
+__device__ __forceinline__ void rf_row(const double2 *__restrict__ tw, Load &ld, Store &st, bool inverse, double *lds)
 {
     double re[S::E], im[S::E];
     int t;
-    rf_row_compute<S>(tw, ld, inverse, lds, t, re, im, after_requests);
+    rf_row_compute<S>(tw, ld, inverse, lds, t, re, im);
     rf_opaque(t);
     // No store before the last butterfly has consumed its twiddles: loads and stores share the in-order vmcnt, and behind
     // a (conditional) store the compiler waits vmcnt(0) for them -- i.e. for the store's own round trip to memory.

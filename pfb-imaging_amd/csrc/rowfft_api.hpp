@@ -84,6 +84,9 @@ void fused_fft_crop(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev,
 // (prep.x != NULL only where fused_pad_takes_prep(): the kernel then keeps the prepared row in LDS; elsewhere -- no room for
 // the row, doubled shapes -- the caller passes a prepared image)
 bool fused_pad_takes_prep(const RowFFT &f, const FusedGeom &g);
+// doubled shapes whose fused kernels park the waiting half transform in LDS (20480 points): fused by default; the others
+// (24576, 32768: the half stays in registers and spills) only with PFBHIP_FUSED_DOUBLED=1
+bool fused_doubled_stashes(const RowFFT &f);
 void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev, const FusedPrep &prep,
                    const FusedPlanes &pl, int do_w, double2 *B_dev, size_t bstride, hipStream_t stream);
 

@@ -179,6 +179,77 @@ def row_block(nrow, rank, world_size):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def partition_rows_by_w(uvw, freq, world_size, plane_cost=1.0, vis_cost=0.0, support=0.125, mask=None):
+    """Rows of ONE band dealt to ``world_size`` ranks as contiguous ranges of |w|: ``[rows_of_rank_0, rows_of_rank_1, ...]``
+    (index arrays into the caller's row axis, each sorted by |w|).
+
+    A w-stacking plan transforms ``P = (w_max - w_min) / dw + W`` planes for the w range of ITS visibilities (w in
+    wavelengths, |w| after the Hermitian fold), whatever their number -- and at BASELINE config 5 (64 planes) the plane
+    transforms are three quarters of an apply.  Time-ordered row blocks all span the full w range, so every rank would
+    transform all the planes; ranges of |w| give rank r about ``P / N + W`` of them.
+
+    The boundaries minimise the largest per-rank cost, in units of one single-GPU apply:
+    ``plane_cost * (span_r / span + support) + vis_cost * nvis_r / nvis`` -- ``span_r`` the range of |w| f over the rank's rows
+    and channels, ``support = W / P0`` the kernel support in units of the single plan's plane count (the planes every rank
+    pays on top of its share of the span), ``plane_cost`` / ``vis_cost`` the plane-transform and scatter / gather shares of a
+    single-GPU apply (0.73 / 0.27 at C5).  Bisection on the maximum with a greedy sweep over the |w|-sorted rows.
+    Deterministic: every rank computes the same partition from the same arrays.
+    """
+    uvw = np.asarray(uvw, dtype=np.float64)
+    freq = np.asarray(freq, dtype=np.float64)
+    nrow = uvw.shape[0]
+    if world_size <= 1 or nrow == 0:
+        return [np.arange(nrow)] + [np.arange(0) for _ in range(max(world_size, 1) - 1)]
+    wabs = np.abs(uvw[:, 2])
+    order = np.argsort(wabs, kind="stable")
+    ws = wabs[order]
+    nvis_row = np.full(nrow, freq.size, dtype=np.float64) if mask is None else np.asarray(mask, dtype=bool).sum(axis=1)[order].astype(np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(nvis_row)])
+    tot = max(cum[-1], 1.0)
+    fmin, fmax = float(freq.min()), float(freq.max())
+    lo_all, hi_all = ws[0] * fmin, ws[-1] * fmax       # span of |w| f over rows x channels (up to the common 1 / c)
+    span = max(hi_all - lo_all, 1e-300)
+    over = float(support)
+    # cost of rows [a, b): plane term from its own span (+ the kernel support), visibility term from its count
+    def cost(a, b):
+        if b <= a:
+            return 0.0
+        return plane_cost * ((ws[b - 1] * fmax - ws[a] * fmin) / span + over) + vis_cost * (cum[b] - cum[a]) / tot
+
+    def sweep(limit):
+        """Greedy: extend each rank's range while its cost stays <= limit; returns the boundaries or None."""
+        bounds, a = [0], 0
+        for _ in range(world_size):
+            lo, hi = a, nrow                            # largest b with cost(a, b) <= limit (cost is monotone in b)
+            if cost(a, min(a + 1, nrow)) > limit and a < nrow:
+                return None
+            while lo < hi:
+                mid = (lo + hi + 1) // 2
+                if cost(a, mid) <= limit:
+                    lo = mid
+                else:
+                    hi = mid - 1
+            a = lo
+            bounds.append(a)
+            if a == nrow:
+                break
+        if bounds[-1] < nrow:
+            return None
+        bounds += [nrow] * (world_size + 1 - len(bounds))
+        return bounds
+
+    lo_c, hi_c = 0.0, cost(0, nrow)
+    best = sweep(hi_c)
+    for _ in range(50):
+        mid = 0.5 * (lo_c + hi_c)
+        got = sweep(mid)
+        if got is None:
+            lo_c = mid
+        else:
+            best, hi_c = got, mid
+    return [order[best[r]:best[r + 1]] for r in range(world_size)]
+
+
 class RowShardedGridder:
     """ONE band's visibilities split into contiguous row blocks, one block per GPU.
 
@@ -198,11 +269,15 @@ class RowShardedGridder:
         self.comm = comm
         self.nrow = uvw.shape[0]
         self.r0, self.r1 = row_block(self.nrow, comm.rank, comm.world_size)
-        sl = slice(self.r0, self.r1)
+        sl = self._select()
         self.local = gridder_cls(uvw[sl], freq, None if mask is None else mask[sl], **kw)
 
+    def _select(self):
+        """The rows of this rank (a slice here; an index array in WShardedGridder)."""
+        return slice(self.r0, self.r1)
+
     def _rows(self, a):
-        return None if a is None else a[self.r0:self.r1]
+        return None if a is None else a[self._select()]
 
     def _device_exchange(self):
         """True when the partial images can stay in HBM between the local gridder and the collective."""
@@ -262,3 +337,34 @@ class RowShardedGridder:
             d.free()
         self._dbuf = None
         self.local.close()
+
+
+class WShardedGridder(RowShardedGridder):
+    """ONE band's visibilities split by |w|: rank r owns a contiguous range of |w| (see :func:`partition_rows_by_w`), hence
+    only the w-planes of that range -- the split of SURVEY.md section 8(e) ("shard w-planes") for a single very large band
+    (BASELINE config 5: 1e8 visibilities, 64 w-planes, 8 GPUs).  Everything else is :class:`RowShardedGridder`: gridding is
+    additive over rows (/root/reference/tests/test_imager_pass2.py:45-63), so the partial images are summed with one
+    ``reduce`` / ``all-reduce`` over xGMI; degridding needs the image on every rank (the caller's broadcast) and no exchange;
+    ``dirty2vis`` returns the model visibilities of ``self.rows`` (this rank's rows, in |w| order).
+
+    ``plane_share`` is the plane-transform share of a single-GPU apply (0.73 at C5, ``profiles/r02f_bench_C5.json``); the
+    rest is attributed to the scatter / gather, which scales with the visibility count.
+    """
+
+    def __init__(self, comm, uvw, freq, mask=None, gridder_cls=None, plane_share=0.73, support_planes=8, planes_estimate=64, **kw):
+        self.parts = partition_rows_by_w(uvw, freq, comm.world_size, plane_cost=plane_share, vis_cost=1.0 - plane_share,
+                                         support=support_planes / max(planes_estimate, 1), mask=mask)
+        self.rows = self.parts[comm.rank] if comm.world_size > 1 else np.arange(uvw.shape[0])
+        super().__init__(comm, uvw, freq, mask, gridder_cls=gridder_cls, **kw)
+
+    def _select(self):
+        return self.rows if self.comm.world_size > 1 else slice(None)   # (one rank: every row, in the caller's order, no copy)
+
+    def planes_per_rank(self):
+        """w-planes of every rank's plan (0 for a stand-in gridder without ``info``), gathered over the communicator."""
+        mine = float(getattr(self.local, "info", {}).get("nplanes", 0)) if hasattr(self.local, "info") else 0.0
+        if self.comm.world_size == 1:
+            return [int(mine)]
+        v = np.zeros(self.comm.world_size)
+        v[self.comm.rank] = mine
+        return [int(p) for p in self.comm.allreduce_sum(v)]

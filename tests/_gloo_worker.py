@@ -204,6 +204,30 @@ def main():
     hr = full.hessian(c["x"], wsum=7.0) + 0.3 * c["x"]
     assert np.linalg.norm(hs - hr) / np.linalg.norm(hr) < 1e-6
 
+    # single band sharded by |w| (the split that shards the w-planes): the two ranks own disjoint, complementary, |w|-ordered
+    # row sets; partial images sum to the unsharded image, each rank degrids its own rows, the Hessian needs one all-reduce
+    from pfb_imaging_amd.parallel import WShardedGridder, partition_rows_by_w
+
+    parts = partition_rows_by_w(c["uvw"], c["freq"], 2, plane_cost=0.73, vis_cost=0.27, support=0.125, mask=c["mask"])
+    assert sorted(np.concatenate(parts).tolist()) == list(range(c["uvw"].shape[0]))
+    wabs = np.abs(c["uvw"][:, 2])
+    assert wabs[parts[0]].max() <= wabs[parts[1]].min() and np.all(np.diff(wabs[parts[1]]) >= 0)
+    span = [wabs[p].max() - wabs[p].min() for p in parts]
+    assert max(span) < 0.75 * (wabs.max() - wabs.min())          # neither rank spans (nearly) the whole w range
+    ws = WShardedGridder(comm, c["uvw"], c["freq"], c["mask"], gridder_cls=OracleGridder, **kw)
+    assert np.array_equal(ws.rows, parts[comm.rank]) and ws.planes_per_rank() == [0, 0]
+    gw = ws.vis2dirty(c["vis"], c["wgt"])
+    assert np.linalg.norm(gw - ref) / np.linalg.norm(ref) < 1e-6
+    mw = ws.dirty2vis(c["x"])
+    refw = full.dirty2vis(c["x"])[ws.rows]
+    assert mw.shape == refw.shape and np.linalg.norm(mw - refw) / np.linalg.norm(refw) < 1e-6
+    ws.set_weights(c["wgt"])
+    hw = ws.hessian(c["x"], eta=0.3, wsum=7.0)
+    assert np.linalg.norm(hw - hr) / np.linalg.norm(hr) < 1e-6
+    # one rank: the partition is everything, in |w| order
+    p1 = partition_rows_by_w(c["uvw"], c["freq"], 1)
+    assert len(p1) == 1 and sorted(p1[0].tolist()) == list(range(c["uvw"].shape[0]))
+
     comm.barrier()
     print(f"rank {comm.rank} ok", flush=True)
 

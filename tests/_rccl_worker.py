@@ -17,7 +17,7 @@ from pfb_imaging_amd.operators.band_worker import BandWorkerPool  # noqa: E402
 from pfb_imaging_amd.operators.hessian import HessPSF, HessTreeRay  # noqa: E402
 from pfb_imaging_amd.operators.psi import PsiNocopyt  # noqa: E402
 from pfb_imaging_amd.opt import L21, PrimalDual, PsfGrad, power_method  # noqa: E402
-from pfb_imaging_amd.parallel import BandComm, RowShardedGridder, local_bands  # noqa: E402
+from pfb_imaging_amd.parallel import BandComm, RowShardedGridder, WShardedGridder, local_bands  # noqa: E402
 from pfb_imaging_amd.utils import synth  # noqa: E402
 from pfb_imaging_amd.wgridder import Gridder  # noqa: E402
 
@@ -105,6 +105,23 @@ def main():
     full.set_weights(c["wgt"])
     assert rel(sh.hessian(c["x"], eta=0.3, wsum=7.0), full.hessian(c["x"], eta=0.3, wsum=7.0)) < 1e-6
     sh.close()
+
+    # --- the same band split by |w| (the split that shards the w-planes): wider field so that the plan stacks ES-kernel planes ---
+    kw2 = dict(kw, pixsize_x=c["cell"] * 120, pixsize_y=c["cell"] * 120)
+    full2 = Gridder(c["uvw"], c["freq"], c["mask"], **kw2)
+    ws = WShardedGridder(comm, c["uvw"], c["freq"], c["mask"], **kw2)
+    planes = ws.planes_per_rank()
+    assert len(planes) == world and planes[rank] == ws.local.info["nplanes"]
+    if world > 1 and full2.info["wmode"] == 0:
+        assert max(planes) < full2.info["nplanes"], (planes, full2.info["nplanes"])   # every rank stacks fewer planes than the whole band
+    dref2 = full2.vis2dirty(c["vis"], c["wgt"])
+    assert rel(ws.vis2dirty(c["vis"], c["wgt"]), dref2) < 1e-6
+    assert rel(ws.dirty2vis(c["x"]), full2.dirty2vis(c["x"])[ws.rows]) < 1e-6
+    ws.set_weights(c["wgt"])
+    full2.set_weights(c["wgt"])
+    assert rel(ws.hessian(c["x"], eta=0.3, wsum=7.0), full2.hessian(c["x"], eta=0.3, wsum=7.0)) < 1e-6
+    ws.close()
+    full2.close()
     full.close()
 
     comm.barrier()

@@ -121,3 +121,35 @@ def test_c3_device_cg_equals_host_loop_on_the_c2_operator(c2):
     assert 0.5 * np.vdot(dev, adev) - np.vdot(b, dev) < 0.0
     # (the stopping rule itself -- relative change of the iterate -- is compared loop against loop at a size where the
     # solve converges in a few iterations: tests/test_gpu_callables.py::test_pcg_family_over_the_device_cg)
+
+
+def test_record_scatter_past_32_bit_record_offsets():
+    """1e8 active visibilities on a plan with polynomial w-planes: the record scatter's byte offsets into the record / value
+    arrays pass 2^32 (32 bytes x 1.34e8 records; 16 bytes x planes x 6.7e7 .. 8.9e7 values).  They used to be absolute 32-bit
+    numbers that wrapped -- silently addressing other visibilities' records -- and are now relative to the wave's first record
+    (csrc/gridder_kernels_mp.hpp, k_grid_rec).  Gridding is additive over rows (tests/test_imager_pass2.py:45-63 of the
+    reference): the image of all rows equals the sum of the images of the two halves, whose plans stay below every wrap point."""
+    from pfb_imaging_amd.wgridder import Gridder
+
+    nrow, nchan, npix = 12_500_000, 8, 256
+    rng = np.random.default_rng(11)
+    c = synth.make_case(nrow, nchan, npix, zscale=0.03, seed=11, with_vis=False)
+    c["cell"] *= 2.0                                                      # (field and w range wide enough for three planes)
+    vis = np.empty((nrow, nchan), dtype=np.complex128)
+    vis.real = rng.standard_normal((nrow, nchan), dtype=np.float32)     # (float32 draws: half the time of float64 ones)
+    vis.imag = rng.standard_normal((nrow, nchan), dtype=np.float32)
+    kw = dict(npix_x=npix, npix_y=npix, pixsize_x=c["cell"], pixsize_y=c["cell"], center_x=0.0, center_y=0.0, epsilon=1e-9,
+              flip_u=False, flip_v=True, flip_w=False, do_wgridding=True, divide_by_n=False, force_wmode=1)
+    g = Gridder(c["uvw"], c["freq"], None, **kw)
+    assert g.info["scatter_mode"] == 2 and g.info["wmode"] == 1 and g.nactive == nrow * nchan, g.info
+    assert g.info["nplanes"] >= 3, g.info
+    assert (g.nactive + 136) * 16 * min(g.info["nplanes"], 4) > 2**32   # the value array is past the old wrap point
+    whole = g.vis2dirty(vis)
+    g.close()
+    parts = np.zeros_like(whole)
+    h = nrow // 2
+    for sl in (slice(0, h), slice(h, nrow)):
+        gp = Gridder(c["uvw"][sl], c["freq"], None, **kw)
+        parts += gp.vis2dirty(vis[sl])
+        gp.close()
+    assert np.linalg.norm(whole - parts) / np.linalg.norm(parts) < 1e-7
