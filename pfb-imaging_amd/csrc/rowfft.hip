@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
             if (do_w) {
                 double s, c;
                 if constexpr (SC) {
-                    fg_screen_poly(g, cc, ss, ix, y, s, c);
+                    fg_screen_poly(g, cc, ss, ix, y, s, c, planes.nsc);
                 } else {
                     double ph = wk * fg_t(g, ix, y);
                     ph -= rint(ph);
@@ -534,6 +534,7 @@ struct PadLoadT {
     const double (&ss)[FUSED_SCMAX];
     int y, do_w;
     double wk;
+    int nsc;  // SC: coefficients the chains evaluate (FusedPlanes::nsc)
     __device__ __forceinline__ double fetch(int u, int) const { return src[max(fg_ix(g, u), 0)]; }
     __device__ __forceinline__ double2 finish(double val, int u, int) const
     {
@@ -542,7 +543,7 @@ struct PadLoadT {
         if (!do_w) return make_double2(val, 0.0);
         double s, c;
         if constexpr (SC) {
-            fg_screen_poly(g, cc, ss, ix, y, s, c);
+            fg_screen_poly(g, cc, ss, ix, y, s, c, nsc);
         } else {
             double ph = wk * fg_t(g, ix, y);
             ph -= rint(ph);
@@ -616,7 +617,7 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
                 cc[q] = SC ? planes.cs[k][q] : 0.0;
                 ss[q] = SC ? planes.sn[k][q] : 0.0;
             }
-            PadLoadT<SC, LROW> ld{LROW ? lrow : dcT + ro, g, cc, ss, y, do_w, planes.w[k]};
+            PadLoadT<SC, LROW> ld{LROW ? lrow : dcT + ro, g, cc, ss, y, do_w, planes.w[k], planes.nsc};
             double re[S::E], im[S::E];
             int t;
             rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im);
@@ -731,7 +732,9 @@ void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl)
             for (int d = 0; d < FUSED_SCMAX; ++d) {
                 long double tail = 0.0L;
                 for (int q = d + 1; q < M / 2; ++q) tail += fabsl(c[size_t(q)]);
-                if (tail <= 2e-17L) { deg = d; break; }
+                // (1e-14 of a unit-modulus screen: five orders below the tightest epsilon a plan accepts; 2e-17 -- the
+                // rounding level -- cost C2 two to three more coefficients per chain)
+                if (tail <= 1e-14L) { deg = d; break; }
             }
             if (deg < 0) return;  // phase too large for a short polynomial: general path
             need = std::max(need, deg + 1);
@@ -753,9 +756,10 @@ void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl)
             mono[size_t(2 * k + part)] = mo;
         }
     if (need > FUSED_SCMAX) return;
-    need = FUSED_SCMAX;  // the kernels evaluate a fixed number of coefficients (leading zeros)
+    const int neval = need <= 4 ? 4 : (need <= 6 ? 6 : FUSED_SCMAX);  // what the kernels evaluate (fg_screen_poly)
+    need = FUSED_SCMAX;  // the arrays hold FUSED_SCMAX coefficients, highest power first, padded with leading zeros
     FusedPlanes trial = pl;
-    trial.nsc = need;
+    trial.nsc = neval;
     for (int k = 0; k < pl.kp; ++k)
         for (int part = 0; part < 2; ++part) {
             const auto &mo = mono[size_t(2 * k + part)];
@@ -781,7 +785,7 @@ void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl)
             worst = std::max(worst, fabsl((long double)cc - cosl(2.0L * pi * ph)));
             worst = std::max(worst, fabsl((long double)ss - sinl(2.0L * pi * ph)));
         }
-    if (worst <= 4e-16L) pl = trial;
+    if (worst <= 1e-13L) pl = trial;
 }
 
 // ---- doubled shapes (N = 2 N1): dedicated fused kernels ---------------------------------------------------
@@ -953,7 +957,7 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
     const size_t ro = size_t(y) * size_t(g.nx);
     const double zc[FUSED_SCMAX] = {};  // (the doubled shapes evaluate the screen the general way)
     for (int k = 0; k < planes.kp; ++k) {
-        PadLoad base{dcT + ro, g, zc, zc, y, do_w, planes.w[k]};  // (the doubled shapes read a PREPARED image: fused_pad_takes_prep)
+        PadLoad base{dcT + ro, g, zc, zc, y, do_w, planes.w[k], 0};  // (the doubled shapes read a PREPARED image: fused_pad_takes_prep)
         PadLoad2 ld_e{base, 0}, ld_o{base, 1};
         double er[S1::E], ei[S1::E], orr[S1::E], oi[S1::E];
         int t;

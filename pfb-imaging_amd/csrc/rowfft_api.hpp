@@ -65,8 +65,9 @@ struct FusedPlanes {
     double w[FUSED_MAXPLANES];  // w of each plane (wavelengths)
     // Narrow fields / small w: cos and sin of the w-screen phase 2 pi w_k (n - 1 + nshift) are themselves low-degree
     // polynomials in s = r2 * za + zb (the abscissa of FusedGeom's n - 1 polynomial): FUSED_SCMAX coefficients each, highest
-    // first (leading zeros), fitted and verified to 4e-16 by fused_planes_fit() (nsc = FUSED_SCMAX); nsc = 0: evaluate
-    // n - 1, then sincos (the general path).
+    // first (leading zeros), fitted to a Chebyshev tail of 1e-14 and verified to 1e-13 by fused_planes_fit(); nsc = 4, 6 or
+    // FUSED_SCMAX = how many of them the kernels evaluate (the rest are the leading zeros); nsc = 0: evaluate n - 1, then
+    // sincos (the general path).
     int nsc = 0;
     double cs[FUSED_MAXPLANES][FUSED_SCMAX] = {};
     double sn[FUSED_MAXPLANES][FUSED_SCMAX] = {};
@@ -146,20 +147,30 @@ __device__ __forceinline__ void fg_sincos2pi(double r, double &sn, double &cs)
 
 // cos / sin of the screen phase at pixel (ix, iy) from a plane's composite polynomials (FusedPlanes::nsc > 0; the caller
 // holds the plane's coefficients in registers)
-__device__ __forceinline__ void fg_screen_poly(const FusedGeom &g, const double (&cc)[FUSED_SCMAX], const double (&ss)[FUSED_SCMAX],
-                                               int ix, int iy, double &sn, double &cs)
+// nsc (wave-uniform: 4, 6 or FUSED_SCMAX) = coefficients that are not leading zeros (FusedPlanes::nsc): the Horner chains start
+// there (round 3: C2's screens need 5-6 coefficients at the 1e-13 the fit is held to, not the 8 the kernels used to evaluate)
+template <int N>
+__device__ __forceinline__ void fg_screen_horner(const double (&cc)[FUSED_SCMAX], const double (&ss)[FUSED_SCMAX], double sv, double &sn,
+                                                 double &cs)
 {
-    const double l = g.lshift + double(ix - g.nx / 2) * g.px;
-    const double m = g.mshift + double(iy - g.ny / 2) * g.py;
-    const double sv = (l * l + m * m) * g.za + g.zb;
-    double c = cc[0], s = ss[0];
+    double c = cc[FUSED_SCMAX - N], s = ss[FUSED_SCMAX - N];
 #pragma unroll
-    for (int j = 1; j < FUSED_SCMAX; ++j) {
+    for (int j = FUSED_SCMAX - N + 1; j < FUSED_SCMAX; ++j) {
         c = c * sv + cc[j];
         s = s * sv + ss[j];
     }
     cs = c;
     sn = s;
+}
+__device__ __forceinline__ void fg_screen_poly(const FusedGeom &g, const double (&cc)[FUSED_SCMAX], const double (&ss)[FUSED_SCMAX],
+                                               int ix, int iy, double &sn, double &cs, int nsc = FUSED_SCMAX)
+{
+    const double l = g.lshift + double(ix - g.nx / 2) * g.px;
+    const double m = g.mshift + double(iy - g.ny / 2) * g.py;
+    const double sv = (l * l + m * m) * g.za + g.zb;
+    if (nsc <= 4) fg_screen_horner<4>(cc, ss, sv, sn, cs);
+    else if (nsc <= 6) fg_screen_horner<6>(cc, ss, sv, sn, cs);
+    else fg_screen_horner<FUSED_SCMAX>(cc, ss, sv, sn, cs);
 }
 
 // image column of uv-column u (-1: u lies in the zero padding)
