@@ -127,6 +127,10 @@ typedef struct pfbhip_gridder_info {
     /* cells of one uv-plane the scatter / gather can touch (tiles with visibilities + halo); the first-axis transforms and
      * the Hessian's plane clear move only these of the occupied rows (0: not computed, every cell of the occupied rows) */
     int64_t used_cells;
+    /* w-screen of the fused second axis, passes (launches of <= 4 planes) per form: composite cos / sin polynomials of the whole
+     * phase (small w x field), separable form (per-plane column table x row factor x residual polynomials), and the rest
+     * (n - 1 polynomial + sincos per pixel and plane) */
+    int32_t screen_composite, screen_separable;
 } pfbhip_gridder_info;
 
 int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw_host /* (nrow,3) */,

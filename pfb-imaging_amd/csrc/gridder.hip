@@ -938,6 +938,7 @@ struct pfbhip_gridder {
     FusedGeom fgeom;  // filled once by create_impl (fused path)
     const FusedGeom &fused_geom() const { return fgeom; }
     std::vector<FusedPlanes> plane_groups;  // per pass of kp_max planes: w and the composite screen polynomials (plan time)
+    DevBuf<double2> d_tau;                  // column tables of the separable screens (FusedPlanes::sep), nplanes x nx
     FusedPlanes fused_planes(int p0, int kp) const
     {
         const size_t grp = size_t(p0 / kp_max);
@@ -1612,9 +1613,6 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     // kernels are the default; PFBHIP_FUSED_DOUBLED=0 / 1 forces the choice for every doubled shape.
     const char *denv = std::getenv("PFBHIP_FUSED_DOUBLED");
     const bool fuse_doubled = denv != nullptr ? denv[0] == '1' : fused_doubled_stashes(g->rowfft_u);
-    g->fused = want_fused && g->rowfft_u.ok && (!g->rowfft_u.pl.doubled || fuse_doubled);
-    if (!own_rows && !g->fused) g->rowfft_u.release();
-    if (own_rows) (void)g->rowfft_v.init(info.nv);
     {  // the screen geometry serves the fused kernels and the separate pad / crop kernels alike
         FusedGeom &fg = g->fgeom;
         fg.nx = int(prm.nx);
@@ -1628,22 +1626,61 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         if (prm.do_wgridding) fused_geom_fit(fg);
         if (prm.verbosity > 0) fprintf(stderr, "[pfbhip] w-screen: n-1 polynomial with %d coefficients\n", fg.npoly);
     }
+    // (the fused kernels evaluate n - 1 by the polynomial only: fields reaching 45 degrees off axis, npoly = 0, keep the
+    // separate pad / crop kernels with the closed form)
+    g->fused = want_fused && g->rowfft_u.ok && (!g->rowfft_u.pl.doubled || fuse_doubled) &&
+               (!prm.do_wgridding || g->fgeom.npoly > 0);
+    if (!own_rows && !g->fused) g->rowfft_u.release();
+    if (own_rows) (void)g->rowfft_v.init(info.nv);
     g->plane_groups.clear();
+    g->d_tau.release();
     if (g->fused) {
+        // screen form per pass: composite polynomials of the whole phase where it is small (PFBHIP_SCREENPOLY=0 disables), else
+        // the separable form (column table x row factor x residual polynomials; PFBHIP_SEPSCREEN=0 disables), else n - 1 and
+        // sincos per pixel and plane
         const char *penv = std::getenv("PFBHIP_SCREENPOLY");
         const bool want = !(penv != nullptr && penv[0] == '0');
+        const char *qenv = std::getenv("PFBHIP_SEPSCREEN");
+        const bool want_sep = !(qenv != nullptr && qenv[0] == '0');
+        bool any_sep = false;
         for (int p0 = 0; p0 < info.nplanes; p0 += g->kp_max) {
             FusedPlanes fp;
             fp.kp = int(std::min<int64_t>(g->kp_max, info.nplanes - p0));
             for (int k = 0; k < FUSED_MAXPLANES; ++k) fp.w[k] = k < fp.kp ? g->wplanes[size_t(p0 + k)] : 0.0;
-            if (want && prm.do_wgridding) fused_planes_fit(g->fgeom, fp);
+            // (the doubled shapes' kernels have the separable and the general form only)
+            if (want && prm.do_wgridding && !g->rowfft_u.pl.doubled) fused_planes_fit(g->fgeom, fp);
+            if (fp.nsc == 0 && want_sep && prm.do_wgridding) fused_planes_fit(g->fgeom, fp, true);
+            any_sep = any_sep || fp.sep != 0;
             g->plane_groups.push_back(fp);
         }
-        if (prm.verbosity > 0 && !g->plane_groups.empty())
-            fprintf(stderr, "[pfbhip] w-screen: composite cos/sin polynomials with %d coefficients\n", g->plane_groups[0].nsc);
+        if (any_sep) {
+            g->d_tau.alloc(size_t(info.nplanes) * size_t(prm.nx));
+            DevBuf<double> d_w(size_t(info.nplanes));
+            PFB_HIP(hipMemcpyAsync(d_w.p, g->wplanes.data(), size_t(info.nplanes) * sizeof(double), hipMemcpyHostToDevice, st));
+            fused_screen_table(g->fgeom, d_w.p, int(info.nplanes), g->d_tau.p, st);
+            PFB_HIP(hipStreamSynchronize(st));
+            for (size_t grp = 0; grp < g->plane_groups.size(); ++grp)
+                g->plane_groups[grp].tau = g->d_tau.p + grp * size_t(g->kp_max) * size_t(prm.nx);
+        }
+        if ((prm.verbosity > 0 || std::getenv("PFBHIP_DEBUG_SCREEN") != nullptr) && !g->plane_groups.empty()) {
+            int n_sc = 0, n_sep = 0, nsc_max = 0;
+            for (const FusedPlanes &fp : g->plane_groups) {
+                n_sc += fp.nsc > 0 && !fp.sep;
+                n_sep += fp.sep != 0;
+                nsc_max = std::max(nsc_max, fp.nsc);
+            }
+            fprintf(stderr, "[pfbhip] w-screen of %zu passes: %d composite cos/sin polynomials, %d separable form, %zu general; <= %d "
+                            "coefficients; n - 1 polynomial %d\n",
+                    g->plane_groups.size(), n_sc, n_sep, g->plane_groups.size() - size_t(n_sc + n_sep), nsc_max, g->fgeom.npoly);
+        }
     }
     info.fft_mode = (g->rowfft_v.ok ? 1 : 0) | (g->fused ? 2 : 0) | ((!g->fused && g->rowfft_u.ok) ? 4 : 0);
     info.screen_poly = g->fgeom.npoly;
+    info.screen_composite = info.screen_separable = 0;
+    for (const FusedPlanes &fp : g->plane_groups) {
+        info.screen_composite += (fp.nsc > 0 && !fp.sep) ? 1 : 0;
+        info.screen_separable += fp.sep ? 1 : 0;
+    }
     info.scatter_mode = g->scatter_rec ? 2 : (g->scatter_blk ? 1 : 0);
     // Row pitch of B.  A workgroup of the transposing first-axis FFT touches B[y][u] for one u and every y: with a pitch of
     // nu * 16 bytes (a multiple of 2^15 for every size the plan picks) all of a row's 16-byte pieces fall on one L2 /

@@ -249,8 +249,9 @@ __device__ __forceinline__ void rf_row2(const double2 *__restrict__ tw, Load &ld
         const double2 lo = make_double2(ere + tr, ei[e] + ti), hi = make_double2(ere - tr, ei[e] - ti);
         st(k1, inverse ? make_double2(lo.y, lo.x) : lo);
         st(k1 + S1::N, inverse ? make_double2(hi.y, hi.x) : hi);
-        // (four combination twiddles requested at a time: all 16 would cost 64 VGPRs.  Computing them as w^t w^(c T) with
-        // scalar-loaded w^(c T) was measured 5-10 % slower on C5: r03g vs r03f)
+        // (four combination twiddles requested at a time: all 16 would cost 64 VGPRs.  Computing them instead -- w^t times a
+        // scalar-loaded w^(c T), r03g, or times the literal 32nd root of unity exp(-i pi c / 16), r03q -- was measured 4-10 %
+        // slower on C5 both times; so was a two-phase form with all stores behind all combinations: 114 spilled VGPRs)
         if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -447,7 +448,7 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
                 if constexpr (SC) {
                     fg_screen_poly(g, cc, ss, ix, y, s, c, planes.nsc);
                 } else {
-                    double ph = wk * fg_t(g, ix, y);
+                    double ph = wk * fg_t_poly(g, ix, y);
                     ph -= rint(ph);
                     fg_sincos2pi(ph, s, c);
                 }
@@ -545,7 +546,7 @@ struct PadLoadT {
         if constexpr (SC) {
             fg_screen_poly(g, cc, ss, ix, y, s, c, nsc);
         } else {
-            double ph = wk * fg_t(g, ix, y);
+            double ph = wk * fg_t_poly(g, ix, y);
             ph -= rint(ph);
             fg_sincos2pi(ph, s, c);
         }
@@ -690,27 +691,33 @@ void fused_geom_fit(FusedGeom &g)
     trial.npoly = deg + 1;
     trial.za = double(2.0L / zmax);
     trial.zb = -1.0;
-    for (int i = 0; i <= deg; ++i) trial.pc[i] = double(mono[size_t(deg - i)]);
+    for (int i = 0; i <= FUSED_MAXPOLY; ++i) trial.pc[i] = 0.0;
+    for (int i = 0; i <= deg; ++i) trial.pc[FUSED_MAXPOLY - deg + i] = double(mono[size_t(deg - i)]);  // right-aligned
     // verify in double arithmetic, as the kernel evaluates it
     long double worst = 0.0L;
     const int NS = 4097;
     for (int j = 0; j < NS; ++j) {
         const double z = double(zmax * j / (NS - 1));
         const double sv = z * trial.za + trial.zb;
-        double acc = trial.pc[0];
-        for (int k = 1; k < trial.npoly; ++k) acc = fma(acc, sv, trial.pc[k]);
+        double acc = trial.pc[FUSED_MAXPOLY + 1 - trial.npoly];
+        for (int k = FUSED_MAXPOLY + 2 - trial.npoly; k <= FUSED_MAXPOLY; ++k) acc = acc * sv + trial.pc[k];
         worst = std::max(worst, fabsl((long double)acc - f((long double)z)));
     }
     if (worst <= 4e-16L * fmax) g = trial;
 }
 
-void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl)
+void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl, bool residual)
 {
     pl.nsc = 0;
+    pl.sep = 0;
     if (g.npoly <= 0 || pl.kp <= 0) return;
     const long double pi = 3.141592653589793238462643383279502884L;
     const long double zmax = 2.0L / (long double)g.za;  // s = r2 * za - 1, r2 in [0, zmax]
-    auto tfun = [&](long double z) { return -z / (1.0L + sqrtl(1.0L - z)) + (long double)g.nshift; };
+    // the whole n - 1 + nshift, or what is left of n - 1 behind its linear term: R(z) = sqrt(1 - z) - 1 + z / 2
+    auto tfun = [&](long double z) {
+        const long double sq = 1.0L + sqrtl(1.0L - z);
+        return residual ? -z * z / (2.0L * sq * sq) : -z / sq + (long double)g.nshift;
+    };
     const int M = 64;
     int need = 0;
     std::vector<std::vector<long double>> mono(size_t(2 * pl.kp));
@@ -760,6 +767,7 @@ void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl)
     need = FUSED_SCMAX;  // the arrays hold FUSED_SCMAX coefficients, highest power first, padded with leading zeros
     FusedPlanes trial = pl;
     trial.nsc = neval;
+    trial.sep = residual ? 1 : 0;
     for (int k = 0; k < pl.kp; ++k)
         for (int part = 0; part < 2; ++part) {
             const auto &mo = mono[size_t(2 * k + part)];
@@ -788,6 +796,26 @@ void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl)
     if (worst <= 1e-13L) pl = trial;
 }
 
+__global__ void k_screen_table(FusedGeom g, const double *w, int nplanes, double2 *tau)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+    if (ix >= g.nx || p >= nplanes) return;
+    const double l = g.lshift + double(ix - g.nx / 2) * g.px;
+    double ph = w[p] * (-0.5 * (l * l));
+    ph -= rint(ph);
+    double sn, cs;
+    fg_sincos2pi(ph, sn, cs);
+    tau[size_t(p) * size_t(g.nx) + size_t(ix)] = make_double2(cs, sn);
+}
+
+void fused_screen_table(const FusedGeom &g, const double *w_dev, int nplanes, double2 *tau_dev, hipStream_t stream)
+{
+    if (nplanes <= 0) return;
+    hipLaunchKernelGGL(k_screen_table, dim3(uint32_t((g.nx + 255) / 256), uint32_t(nplanes)), dim3(256), 0, stream, g, w_dev, nplanes,
+                       tau_dev);
+    PFB_HIP(hipGetLastError());
+}
+
 // ---- doubled shapes (N = 2 N1): dedicated fused kernels ---------------------------------------------------
 // The generic kernels above on RfShape2 materialise all 2 x 16 outputs per thread (128 VGPRs) next to the
 // waiting half transform and spill ~250 registers.  Here the even / odd half transforms are combined pair by
@@ -809,7 +837,8 @@ struct OccLoad2 {
 // transform the kernel spilled ~100 VGPRs and lost to the unfused path (36.8 vs 35.6 ms per 4 planes at C5's size).  The
 // epilogue requests the running sum / correction / beam / x of FOUR outputs at a time from clamped addresses, one group ahead
 // (see k_fused_fft_crop), and stores after the last group.
-template <class S1, bool STASH>
+// MODE 0: n - 1 polynomial + sincos per pixel and plane; 2: separable screen (FusedPlanes::sep: table + row factor + residual)
+template <class S1, bool STASH, int MODE>
 __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
     k_fused_fft_crop2(const double2 *tw, FusedGeom g, const uint8_t *occ, const double2 *B, size_t bstride, FusedPlanes planes,
                       int do_w, int first, double *accT, FusedFinal fin)
@@ -821,7 +850,6 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
     // samples 2 pos and 2 pos + 1 lie in the same 32-column block: one occupancy mask serves both halves
     uint32_t mask = 0;
     rf_for_each_load<S1>(int(threadIdx.x), [&](int pos, int slot) { mask |= (occ[(2 * pos) >> 5] ? 1u : 0u) << slot; });
-    const double2 *__restrict__ tw2 = tw + S1::N;
     for (int k = 0; k < planes.kp; ++k) {
         const double2 *row = B + size_t(k) * bstride + size_t(y) * size_t(g.bpitch);
         OccLoad2 ld_e{row, mask, 0}, ld_o{row, mask, 1};
@@ -840,88 +868,119 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
             for (int e = 0; e < S1::E; ++e) rf_lds[e * S1::T + t] = ei[e];
         }
         const double wk = planes.w[k];
+        double cc[FUSED_SCMAX], ss[FUSED_SCMAX];  // MODE 2: the plane's residual polynomials, its row factor and its table
+        double rs = 0.0, rc = 1.0;
+        const double2 *trow = nullptr;
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int q = 0; q < FUSED_SCMAX; ++q) {
+                cc[q] = planes.cs[k][q];
+                ss[q] = planes.sn[k][q];
+            }
+            fg_row_factor(g, wk, y, rs, rc);
+            trow = planes.tau + size_t(k) * size_t(g.nx);
+        }
         const bool last = k == planes.kp - 1;
         const bool add_img = !(first && k == 0);
         const bool finalize = last && fin.corr != nullptr;
         const size_t ro = size_t(y) * size_t(g.nx);
-        const bool has_beam = finalize && fin.beam != nullptr, has_x = finalize && fin.x != nullptr;
-        const double *crow = finalize ? fin.corr + ro : arow;
-        const double *brow = has_beam ? fin.beam + ro : crow;
-        const double *xrow = has_x ? fin.x + ro : crow;
-        // group = one slot e = two outputs (k1 and k1 + N1)
-        constexpr int NG = S1::E;
-        double qi[2][2], qc[2][2], qb[2][2], qx[2][2];
-        auto request = [&](int e0, int buf) {
+        // The epilogue exists twice: FIN = false (all planes but the band's last) requests only the running sum, FIN = true also
+        // the correction, beam and x.  One body for both kept 12 more request registers live on every plane, and the spill
+        // reloads they caused (scratch loads wait on vmcnt(0)) drained the next group's requests each time.
+        const double2 *__restrict__ tw2 = tw + S1::N;
+        auto epilogue = [&](auto fin_tag) {
+            constexpr bool FIN = decltype(fin_tag)::value;
+            const bool has_beam = FIN && fin.beam != nullptr, has_x = FIN && fin.x != nullptr;
+            const double *crow = FIN ? fin.corr + ro : arow;
+            const double *brow = has_beam ? fin.beam + ro : crow;
+            const double *xrow = has_x ? fin.x + ro : crow;
+            // group = one slot e = two outputs (k1 and k1 + N1)
+            constexpr int NG = S1::E;
+            double qi[2][2], qc[2][2], qb[2][2], qx[2][2];
+            double2 qt[2][2], qw[2];  // (the combination twiddle travels with the requests: loaded inside its group it was the
+                                      // youngest load in flight, and waiting for it -- vmcnt(0) -- drained the next group's requests)
+            auto request = [&](int e0, int buf) {
+                qw[buf] = tw2[S1::out_pos(t, e0)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int ixc = max(fg_ix(g, S1::out_pos(t, e0) + j * S1::N), 0);
-                qi[buf][j] = arow[ixc];
-                qc[buf][j] = crow[ixc];
-                qb[buf][j] = brow[ixc];
-                qx[buf][j] = xrow[ixc];
-            }
-        };
-        request(0, 0);
-        // results wait in the LDS cells their slot's parked values leave behind (STASH), else in registers, and are stored
-        // after the last group
-        double res[STASH ? 2 * (S1::E - NST) + 1 : 2 * S1::E];
-#pragma unroll
-        for (int gq = 0; gq < NG; ++gq) {
-            if (gq + 1 < NG) request(gq + 1, (gq + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const int e = gq;
-                const int k1 = S1::out_pos(t, e);
-                const double2 w = tw2[k1];
-                const double ere = e < NST ? stash[e * S1::T + t] : er[e], eim = STASH ? rf_lds[e * S1::T + t] : ei[e];
-                const double tr = orr[e] * w.x - oi[e] * w.y, ti = orr[e] * w.y + oi[e] * w.x;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const double vre = h ? ere - tr : ere + tr, vim = h ? eim - ti : eim + ti;
-                    const int ix = fg_ix(g, k1 + h * S1::N);
-                    const int j = h;
-                    double v = 0.0;
-                    if (ix >= 0) {
-                        double r = vim;  // inverse transform: value = (im, re)
-                        if (do_w) {
-                            double ph = wk * fg_t(g, ix, y);
-                            ph -= rint(ph);
-                            double sn, cs;
-                            fg_sincos2pi(ph, sn, cs);
-                            r = vim * cs + vre * sn;
-                        }
-                        if (add_img) r += qi[gq & 1][j];
-                        if (finalize) {
-                            const double c = has_beam ? qc[gq & 1][j] * qb[gq & 1][j] : qc[gq & 1][j];
-                            v = r * c * fin.scale;
-                            if (has_x) v += fin.eta * qx[gq & 1][j];
-                        } else {
-                            v = r;
-                        }
+                for (int j = 0; j < 2; ++j) {
+                    const int ixc = max(fg_ix(g, S1::out_pos(t, e0) + j * S1::N), 0);
+                    qi[buf][j] = arow[ixc];
+                    if constexpr (FIN) {
+                        qc[buf][j] = crow[ixc];
+                        qb[buf][j] = brow[ixc];
+                        qx[buf][j] = xrow[ixc];
                     }
-                    if constexpr (STASH) {
-                        if (h == 1) rf_lds[e * S1::T + t] = v;
-                        else if (e < NST) stash[e * S1::T + t] = v;
-                        else res[2 * (e - NST)] = v;
-                    } else {
-                        res[2 * e + h] = v;
+                    if constexpr (MODE == 2) qt[buf][j] = trow[ixc];
+                }
+            };
+            request(0, 0);
+            // results wait in the LDS cells their slot's parked values leave behind (STASH), else in registers, and are stored
+            // after the last group
+            double res[STASH ? 2 * (S1::E - NST) + 1 : 2 * S1::E];
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                if (gq + 1 < NG) request(gq + 1, (gq + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int e = gq;
+                    const int k1 = S1::out_pos(t, e);
+                    const double2 w = qw[gq & 1];
+                    const double ere = e < NST ? stash[e * S1::T + t] : er[e], eim = STASH ? rf_lds[e * S1::T + t] : ei[e];
+                    const double tr = orr[e] * w.x - oi[e] * w.y, ti = orr[e] * w.y + oi[e] * w.x;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const double vre = h ? ere - tr : ere + tr, vim = h ? eim - ti : eim + ti;
+                        const int ix = fg_ix(g, k1 + h * S1::N);
+                        const int j = h;
+                        double v = 0.0;
+                        if (ix >= 0) {
+                            double r = vim;  // inverse transform: value = (im, re)
+                            if (do_w) {
+                                double sn, cs;
+                                if constexpr (MODE == 2) {
+                                    fg_screen_sep(g, cc, ss, ix, y, qt[gq & 1][j], rs, rc, sn, cs, planes.nsc);
+                                } else {
+                                    double ph = wk * fg_t_poly(g, ix, y);
+                                    ph -= rint(ph);
+                                    fg_sincos2pi(ph, sn, cs);
+                                }
+                                r = vim * cs + vre * sn;
+                            }
+                            if (add_img) r += qi[gq & 1][j];
+                            if constexpr (FIN) {
+                                const double c = has_beam ? qc[gq & 1][j] * qb[gq & 1][j] : qc[gq & 1][j];
+                                v = r * c * fin.scale;
+                                if (has_x) v += fin.eta * qx[gq & 1][j];
+                            } else {
+                                v = r;
+                            }
+                        }
+                        if constexpr (STASH) {
+                            if (h == 1) rf_lds[e * S1::T + t] = v;
+                            else if (e < NST) stash[e * S1::T + t] = v;
+                            else res[2 * (e - NST)] = v;
+                        } else {
+                            res[2 * e + h] = v;
+                        }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        double *orow = finalize ? fin.out + ro : arow;
+            double *orow = FIN ? fin.out + ro : arow;
 #pragma unroll
-        for (int e = 0; e < S1::E; ++e) {
+            for (int e = 0; e < S1::E; ++e) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int ix = fg_ix(g, S1::out_pos(t, e) + h * S1::N);
-                double v;
-                if constexpr (STASH) v = h == 1 ? rf_lds[e * S1::T + t] : (e < NST ? stash[e * S1::T + t] : res[2 * (e - NST)]);
-                else v = res[2 * e + h];
-                if (ix >= 0) orow[ix] = v;
+                for (int h = 0; h < 2; ++h) {
+                    const int ix = fg_ix(g, S1::out_pos(t, e) + h * S1::N);
+                    double v;
+                    if constexpr (STASH) v = h == 1 ? rf_lds[e * S1::T + t] : (e < NST ? stash[e * S1::T + t] : res[2 * (e - NST)]);
+                    else v = res[2 * e + h];
+                    if (ix >= 0) orow[ix] = v;
+                }
             }
-        }
+        };
+        if (finalize) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
         if constexpr (STASH) rf_barrier();  // the next plane's transform writes the exchange buffer (the parked ei of slow waves)
     }
 }
@@ -953,7 +1012,6 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
         omask |= (occ[k1 >> 5] ? 1u : 0u) << e;
         omask |= (occ[(k1 + S1::N) >> 5] ? 1u : 0u) << (16 + e);
     }
-    const double2 *__restrict__ tw2 = tw + S1::N;
     const size_t ro = size_t(y) * size_t(g.nx);
     const double zc[FUSED_SCMAX] = {};  // (the doubled shapes evaluate the screen the general way)
     for (int k = 0; k < planes.kp; ++k) {
@@ -972,6 +1030,7 @@ __global__ void __launch_bounds__(S1::T, ((S1::T + 63) / 64 + 3) / 4)
         // B[y][u], or Bt[u][y] for the transposing first axis (g.tpitch > 0)
         double2 *bbase = B + size_t(k) * bstride + (g.tpitch > 0 ? size_t(y) : size_t(y) * size_t(g.bpitch));
         const size_t ustep = g.tpitch > 0 ? size_t(g.tpitch) : size_t(1);
+        const double2 *__restrict__ tw2 = tw + S1::N;
 #pragma unroll
         for (int e = 0; e < S1::E; ++e) {
             const int k1 = S1::out_pos(t, e);
@@ -990,12 +1049,18 @@ static void launch_crop2(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t
                          const FusedPlanes &planes, int do_w, bool first, double *accT_dev, const FusedFinal &fin,
                          hipStream_t stream)
 {
-    static bool attr = false;
+    static bool attr = false, attr_sep = false;
     constexpr bool STASH = rf_stash_slots<S1>() > 0;
-    rf_allow_lds(&k_fused_fft_crop2<S1, STASH>, &attr);
-    hipLaunchKernelGGL((k_fused_fft_crop2<S1, STASH>), dim3(uint32_t(g.ny)), dim3(S1::T),
-                       size_t(S1::LDS_BYTES) + size_t(rf_stash_slots<S1>()) * S1::T * sizeof(double), stream,
-                       pl.twiddle, g, occ_dev, B_dev, bstride, planes, do_w, first ? 1 : 0, accT_dev, fin);
+    const size_t lds = size_t(S1::LDS_BYTES) + size_t(rf_stash_slots<S1>()) * S1::T * sizeof(double);
+    if (planes.sep && planes.nsc > 0 && do_w) {
+        rf_allow_lds(&k_fused_fft_crop2<S1, STASH, 2>, &attr_sep);
+        hipLaunchKernelGGL((k_fused_fft_crop2<S1, STASH, 2>), dim3(uint32_t(g.ny)), dim3(S1::T), lds, stream, pl.twiddle, g, occ_dev,
+                           B_dev, bstride, planes, do_w, first ? 1 : 0, accT_dev, fin);
+        return;
+    }
+    rf_allow_lds(&k_fused_fft_crop2<S1, STASH, 0>, &attr);
+    hipLaunchKernelGGL((k_fused_fft_crop2<S1, STASH, 0>), dim3(uint32_t(g.ny)), dim3(S1::T), lds, stream, pl.twiddle, g, occ_dev,
+                       B_dev, bstride, planes, do_w, first ? 1 : 0, accT_dev, fin);
 }
 template <class S1>
 static void launch_pad2(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *occ_dev, const double *dcT_dev,
@@ -1029,7 +1094,7 @@ static void launch_crop(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t 
     static bool attr = false, attr_sc = false;
     const bool row = fused_row_fits(S::LDS_BYTES, g.nx) && planes.kp > 1;
     const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
-    if (planes.nsc > 0 && do_w) {
+    if (planes.nsc > 0 && !planes.sep && do_w) {
         rf_allow_lds(&k_fused_fft_crop<S, true>, &attr_sc);
         hipLaunchKernelGGL((k_fused_fft_crop<S, true>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, B_dev,
                            bstride, planes, do_w, first ? 1 : 0, row ? 1 : 0, accT_dev, fin);
@@ -1049,7 +1114,7 @@ static void launch_pad(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *
     const bool row = fused_row_fits(S::LDS_BYTES, g.nx);
     PFB_REQUIRE(row || prep.x == nullptr, "fused pad kernel without an LDS row needs a prepared image (fused_pad_takes_prep)");
     const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
-    if (planes.nsc > 0 && do_w) {
+    if (planes.nsc > 0 && !planes.sep && do_w) {
         rf_allow_lds(&k_fused_pad_fft<S, true>, &attr_sc);
         hipLaunchKernelGGL((k_fused_pad_fft<S, true>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,
                            prep, planes, do_w, row ? 1 : 0, B_dev, bstride);

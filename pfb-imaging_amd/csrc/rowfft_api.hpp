@@ -33,13 +33,16 @@ void rowfft_b2a(const RowFFTPlan &pl, const double2 *B_dev, double2 *A_dev, cons
 
 // Geometry of the second-axis (u) pass of the gridder's plane transform.
 constexpr int FUSED_MAXPOLY = 20;
+constexpr int FUSED_TSHORT = 8;  // coefficient count up to which the short Horner chain serves (fields up to ~10 degrees)
 struct FusedGeom {
     int nx, ny, nu;
     int bpitch;  // complex elements between consecutive rows of B (>= nu; padded off the power-of-two pitch, see gridder.hip)
     int tpitch;  // > 0: the fused pad kernel stores TRANSPOSED, Bt[u][y] with this many elements per row u (0: B[y][u])
     double px, py, lshift, mshift, nshift;
-    // n - 1 = sqrt(1 - r2) - 1 as a polynomial in s = r2 * za + zb in [-1, 1] (npoly coefficients, highest
-    // first); npoly = 0: evaluate the square root (wide fields).  Filled by fused_geom_fit().
+    // n - 1 = sqrt(1 - r2) - 1 as a polynomial in s = r2 * za + zb in [-1, 1]: npoly coefficients, highest first, RIGHT-ALIGNED
+    // in pc (pc[FUSED_MAXPOLY + 1 - npoly ..], zeros in front: the kernels run fixed-length Horner chains over the last
+    // FUSED_TSHORT or all FUSED_MAXPOLY + 1 entries, see fg_t); npoly = 0: evaluate the square root (fields wider than 45
+    // degrees; the fused kernels are not used then).  Filled by fused_geom_fit().
     int npoly = 0;
     double za = 0.0, zb = 0.0;
     double pc[FUSED_MAXPOLY + 1] = {};
@@ -71,9 +74,20 @@ struct FusedPlanes {
     int nsc = 0;
     double cs[FUSED_MAXPLANES][FUSED_SCMAX] = {};
     double sn[FUSED_MAXPLANES][FUSED_SCMAX] = {};
+    // Larger phases (ES-kernel plane stacks; round 3): SEPARABLE form.  With n - 1 = -z/2 + R(z), z = l^2 + m^2, R = O(z^2 / 8),
+    //   exp(2 pi i w (n - 1 + nshift)) = rho(y) * tau[ix] * exp(2 pi i w R(z)),
+    // rho = cis(2 pi w (nshift - m^2 / 2)) one sincos per row and plane, tau[ix] = cis(-pi w l(ix)^2) a per-plane TABLE over
+    // the image columns (fused_screen_table; nx entries per plane, L2-resident, the same for every row) and the residual a
+    // short polynomial pair in s again (cs / sn / nsc above, fitted to w R(z)).  sep = 1: cs / sn hold the residual and
+    // tau points at the table of plane 0 of this group (plane k at tau + k * nx).
+    int sep = 0;
+    const double2 *tau = nullptr;
 };
 // Fills pl.nsc / cs / sn for the planes pl.w[0..kp) over the field of view of g (g.npoly > 0 required), or leaves nsc = 0.
-void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl);
+// residual = false: the whole screen (pl.sep = 0); true: the residual of the separable form (pl.sep = 1; the caller sets tau).
+void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl, bool residual = false);
+// tau[p * g.nx + ix] = cis(-pi w[p] l(ix)^2) for nplanes planes (device arrays)
+void fused_screen_table(const FusedGeom &g, const double *w_dev, int nplanes, double2 *tau_dev, hipStream_t stream);
 
 // grid side: for every image row y and every plane k < kp: inverse row FFT of B_k[y][:] (blocks of 32
 // columns that are not occupied are taken as zero without being read), then
@@ -95,17 +109,31 @@ void fused_pad_fft(const RowFFT &f, const FusedGeom &g, const uint8_t *occ_dev, 
 // ---- w-screen helpers shared by the fused kernels (rowfft.hip) and the separate pad / crop kernels (gridder.hip) ----
 // n - 1 + nshift at image pixel (ix, iy): polynomial in r2 where the field is narrow enough for
 // fused_geom_fit(), the numerically stable closed form otherwise
-__device__ __forceinline__ double fg_t(const FusedGeom &g, int ix, int iy)
+// Round 3: the polynomial used to be a run-time loop over g.pc -- one dependent scalar load from the kernel-argument segment
+// per coefficient and pixel (C5's fused second axis spent a third of its time there).  The chains are now of fixed length with
+// compile-time indices, so the coefficients are loop-invariant scalars.
+template <int NC>
+__device__ __forceinline__ double fg_t_horner(const FusedGeom &g, double sv)
+{
+    double acc = g.pc[FUSED_MAXPOLY + 1 - NC];
+#pragma unroll
+    for (int k = FUSED_MAXPOLY + 2 - NC; k <= FUSED_MAXPOLY; ++k) acc = acc * sv + g.pc[k];
+    return acc;
+}
+// (g.npoly > 0: what the fused kernels require)
+__device__ __forceinline__ double fg_t_poly(const FusedGeom &g, int ix, int iy)
 {
     const double l = g.lshift + double(ix - g.nx / 2) * g.px;
     const double m = g.mshift + double(iy - g.ny / 2) * g.py;
+    const double sv = (l * l + m * m) * g.za + g.zb;
+    return (g.npoly <= FUSED_TSHORT ? fg_t_horner<FUSED_TSHORT>(g, sv) : fg_t_horner<FUSED_MAXPOLY + 1>(g, sv)) + g.nshift;
+}
+__device__ __forceinline__ double fg_t(const FusedGeom &g, int ix, int iy)
+{
+    if (g.npoly > 0) return fg_t_poly(g, ix, iy);
+    const double l = g.lshift + double(ix - g.nx / 2) * g.px;
+    const double m = g.mshift + double(iy - g.ny / 2) * g.py;
     const double r2 = l * l + m * m;
-    if (g.npoly > 0) {
-        const double sv = r2 * g.za + g.zb;
-        double acc = g.pc[0];
-        for (int k = 1; k < g.npoly; ++k) acc = acc * sv + g.pc[k];
-        return acc + g.nshift;
-    }
     if (r2 <= 1.0) return -r2 / (1.0 + sqrt(1.0 - r2)) + g.nshift;
     return -sqrt(r2 - 1.0) - 1.0 + g.nshift;
 }
@@ -171,6 +199,25 @@ __device__ __forceinline__ void fg_screen_poly(const FusedGeom &g, const double 
     if (nsc <= 4) fg_screen_horner<4>(cc, ss, sv, sn, cs);
     else if (nsc <= 6) fg_screen_horner<6>(cc, ss, sv, sn, cs);
     else fg_screen_horner<FUSED_SCMAX>(cc, ss, sv, sn, cs);
+}
+
+// separable form (FusedPlanes::sep): the row factor rho of plane w at image row iy, and the screen (sn, cs) of a pixel from the
+// residual polynomials, the table value and rho
+__device__ __forceinline__ void fg_row_factor(const FusedGeom &g, double w, int iy, double &rs, double &rc)
+{
+    const double m = g.mshift + double(iy - g.ny / 2) * g.py;
+    double ph = w * (g.nshift - 0.5 * (m * m));
+    ph -= rint(ph);
+    fg_sincos2pi(ph, rs, rc);
+}
+__device__ __forceinline__ void fg_screen_sep(const FusedGeom &g, const double (&cc)[FUSED_SCMAX], const double (&ss)[FUSED_SCMAX],
+                                              int ix, int iy, double2 tau, double rs, double rc, double &sn, double &cs, int nsc)
+{
+    double s, c;
+    fg_screen_poly(g, cc, ss, ix, iy, s, c, nsc);
+    const double tc = rc * tau.x - rs * tau.y, ts = rc * tau.y + rs * tau.x;
+    cs = tc * c - ts * s;
+    sn = tc * s + ts * c;
 }
 
 // image column of uv-column u (-1: u lies in the zero padding)

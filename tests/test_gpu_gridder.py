@@ -527,6 +527,38 @@ def test_doubled_fft_shapes_vs_oracle(nx, ny, monkeypatch):
     assert rel(d1, d) < 1e-11 and rel(v1, v) < 1e-11 and rel(h1, h) < 1e-11
 
 
+def test_separable_screen_matches_general_form(monkeypatch):
+    """The w-screen of a pass in separable form (per-plane column table x row factor x residual polynomials,
+    csrc/rowfft_api.hpp FusedPlanes::sep) against the same plan with n - 1 and sincos per pixel (PFBHIP_SEPSCREEN=0),
+    and against the oracle: a 20480-point fused axis, ES-kernel planes, shifted phase centre, beam and eta."""
+    c = make(nrow=1500, npix=64, widen=8.0, zscale=0.4)
+    rng = np.random.default_rng(16)
+    nx, ny = 14000, 900
+    c["nx"], c["ny"] = nx, ny
+    c["cell"] = c["cell"] * 64.0 / max(nx, ny)
+    c["x"] = rng.standard_normal((nx, ny))
+    center = (3e-3, -2e-3)
+    monkeypatch.delenv("PFBHIP_SEPSCREEN", raising=False)
+    g, kw, mask = gpu_plan(c, center_x=center[0], center_y=center[1])
+    assert g.info["nu"] == 20480 and g.info["fft_mode"] & 2, g.info
+    assert g.info["screen_separable"] > 0, g.info
+    o = oracle_plan(c, g, kw, mask)
+    d = g.vis2dirty(c["vis"], c["wgt"])
+    assert rel(d, o.vis2dirty(c["vis"], c["wgt"])) < 2e-9
+    beam = 1.0 + 0.1 * rng.random((nx, ny))
+    g.set_weights(c["wgt"])
+    h = g.hessian(c["x"], beam=beam, eta=0.3, wsum=7.0)
+    g.close()
+    monkeypatch.setenv("PFBHIP_SEPSCREEN", "0")
+    g0, _, _ = gpu_plan(c, center_x=center[0], center_y=center[1])
+    assert g0.info["screen_separable"] == 0, g0.info
+    d0 = g0.vis2dirty(c["vis"], c["wgt"])
+    g0.set_weights(c["wgt"])
+    h0 = g0.hessian(c["x"], beam=beam, eta=0.3, wsum=7.0)
+    g0.close()
+    assert rel(d, d0) < 1e-11 and rel(h, h0) < 1e-11
+
+
 @pytest.mark.parametrize("eps", [1e-4, 1e-10])
 def test_epsilon_contract_own_fft_path(eps):
     """Accuracy contract at both ends of the range on a grid the hand-written FFT path serves (>= 1024)."""
