@@ -273,16 +273,32 @@ __device__ __forceinline__ void blk_tile_to_grid(const GroupArgs &ga, const Work
         for (int j = 0; j < NJ; ++j)
             if (lo[j] >= 0) v[k][j] = gk[off[j]];
     }
+    // Every sum is formed before the first store (round 3).  With the add and the store of a cell together under `if (nonzero)`
+    // the compiler had to wait again for "possibly outstanding" loads behind the first stores, and since loads and stores share
+    // the in-order vmcnt that wait covered the stores' own round trips -- twice per flush in the ISA.
+    // (and the wait for the loads is spelled out, unconditionally: left to the compiler it sits inside the first `if`, and every
+    // later block has to assume it was skipped)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    uint32_t nz = 0;
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
-        double2 *gk = grid + size_t(k) * ga.plane_stride;
         const double *lre = lds + (2 * k) * LL, *lim = lds + (2 * k + 1) * LL;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             if (lo[j] >= 0) {
                 const double re = lre[lo[j]], im = lim[lo[j]];
-                if (re != 0.0 || im != 0.0) gk[off[j]] = make_double2(v[k][j].x + re, v[k][j].y + im);
+                v[k][j].x += re;
+                v[k][j].y += im;
+                nz |= (re != 0.0 || im != 0.0) ? 1u << (k * NJ + j) : 0u;
             }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        double2 *gk = grid + size_t(k) * ga.plane_stride;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if ((nz >> (k * NJ + j)) & 1u) gk[off[j]] = v[k][j];
     }
 }
 
