@@ -692,6 +692,7 @@ struct pfbhip_gridder {
     // of the current apply (kp_max per visibility), written by the gather inside a Hessian apply (pval_ready) or by
     // k_plane_values in front of the scatter
     bool scatter_rec = false, pval_ready = false, want_pval = false;
+    bool pval_from_gather = false;  // single-pass plans: the gather's epilogue writes the scatter's values inside a Hessian apply
     DevBuf<VisRec> d_rec;
     // row-walk gather (k_degrid_rw): same plans as the record scatter; d_kw: plane weights of every visibility (plan time)
     bool gather_rw = false;
@@ -718,8 +719,11 @@ struct pfbhip_gridder {
             const size_t grp = work_off.size() > 1 ? size_t(plane0 / kp_max) : 0;
             if (scatter_rec && !pval_ready) {
                 timer.begin(5);
-                hipLaunchKernelGGL((k_plane_values<W>), dim3(uint32_t(ceil_div(info.nactive, 256))), dim3(256), 0, stream, ga,
-                                   info.nactive, sval, d_pval.p);
+                if (prm.do_wgridding && info.wmode == 0)
+                    hipLaunchKernelGGL((k_plane_values_es<W>), dim3(ga.a.nwork), dim3(256), 0, stream, ga, sval, d_pval.p);
+                else
+                    hipLaunchKernelGGL((k_plane_values<W>), dim3(uint32_t(ceil_div(info.nactive, 256))), dim3(256), 0, stream, ga,
+                                       info.nactive, sval, d_pval.p);
                 timer.end();
             }
             for (int col = 0; col < 4; ++col) {  // one launch per tile colour (see blk_tile_to_grid)
@@ -1427,7 +1431,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         // (mean over the passes: the first and last pass of an ES-plane plan hold the few visibilities at the ends of the w
         // range -- their launches are short whichever kernel runs them)
         const size_t per_pass = work.size() / std::max<size_t>(g->work_cnt.size(), 1);
-        if (g->scatter_blk && smode != "block" && smode != "rec" && per_pass < size_t(2048)) g->scatter_blk = false;
+        if (g->scatter_blk && smode != "block" && smode != "rec" && smode != "rec_es" && per_pass < size_t(2048)) g->scatter_blk = false;
     }
     {
         // colour slices of every group's list (LPT order kept inside a slice); chunks of a tile that has several in the
@@ -1466,14 +1470,21 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         PFB_HIP(hipStreamSynchronize(st));  // wcol is a local
     }
     const bool rec_mode = info.nplanes <= g->kp_max && (!prm.do_wgridding || info.wmode == 1) && info.nactive > 0 && !work.empty();
-    g->scatter_rec = rec_mode && g->scatter_blk && smode != "block";
+    // ES-kernel plane stacks (round 3): the record scatter with the values of each pass written by k_plane_values_es in front of
+    // it, ONLY with PFBHIP_SCATTER=rec_es.  Measured (gpurun_out/r03w, r03x): 8192^2 image, 19 planes, 9.5e6 visibilities: scatter
+    // 21.2 -> 17.8 ms, + 1.4 ms of plane values (88 bytes per visibility and pass), apply 73.2 -> 70.9 ms; C5: 195 -> 190 ms,
+    // + 13 ms of plane values, apply 1035 -> 1044 ms -- there the scatter waits on the records / values of 1e8 visibilities
+    // (6 GB per pass set) whichever kernel runs.  No rule that separates the two cases was found; k_grid_blk stays the default.
+    const bool rec_es = prm.do_wgridding && info.wmode == 0 && info.nactive > 0 && !work.empty() && smode == "rec_es";
+    g->scatter_rec = (rec_mode || rec_es) && g->scatter_blk && smode != "block";
+    g->pval_from_gather = rec_mode && g->scatter_rec;
     {
         const char *genv = std::getenv("PFBHIP_GATHER");
         g->gather_rw = rec_mode && !(genv != nullptr && std::string(genv) == "walk");
         const char *denv = std::getenv("PFBHIP_RW_DEPTH");
         g->rw_depth = denv != nullptr ? std::max(0, std::min(3, std::atoi(denv))) : 0;
     }
-    if (rec_mode) {
+    if (rec_mode || g->scatter_rec) {
         g->d_rec.alloc(size_t(info.nactive) + REC_PAD);
         g->d_pval.alloc((size_t(info.nactive) + REC_PAD) * size_t(g->kp_max));
         PFB_HIP(hipMemsetAsync(g->d_pval.p, 0, g->d_pval.bytes(), st));
@@ -2097,7 +2108,7 @@ static void hessian_dev_impl(pfbhip_gridder *g, const double *x_dev, const doubl
     g->side_clear_pending = side;
     g->side_clear_done = false;
     // record scatter: the gather's epilogue writes the weighted, plane-weighted model visibilities (no sacc, no scaling pass)
-    g->want_pval = g->scatter_rec && g->info.nwork > 0;
+    g->want_pval = g->pval_from_gather && g->info.nwork > 0;
     struct ClearFlags {
         pfbhip_gridder *g;
         ~ClearFlags() { g->want_pval = g->pval_ready = false; }

@@ -1053,6 +1053,38 @@ __global__ void k_plane_values(GroupArgs ga, int64_t nactive, const double2 *__r
     }
 }
 
+// The same for one pass of an ES-kernel plane stack (round 3: the record scatter serves multi-pass plans too), driven by the
+// pass's WORK LIST (one workgroup per work item, all colours): with the plane-sorted order a pass's items hold exactly the
+// visibilities whose W planes meet its planes [a.plane, a.plane + kp), so a pass costs what it scatters, not nactive; plans with
+// too few planes for that order walk every visibility in every pass, zeros included.
+template <int W>
+__global__ void __launch_bounds__(256) k_plane_values_es(GroupArgs ga, const double2 *__restrict__ sval, double2 *__restrict__ pval)
+{
+    constexpr int D = kernel_poly_degree_c(W);
+    const PlaneArgs &a = ga.a;
+    if (blockIdx.x >= a.nwork) return;
+    const WorkItem wi = a.work[blockIdx.x];
+    const double shift = 1.0 - 0.5 * double(W);
+    for (uint32_t j = wi.begin + threadIdx.x; j < wi.end; j += blockDim.x) {
+        const double pws = a.pw[j] + shift;
+        const double fl = floor(pws);
+        const int dp0 = a.plane - int(fl);  // the pass's first plane relative to the visibility's first plane
+        const double z = 2.0 * (pws - fl) - 1.0;
+        const double2 val = sval[j];
+        for (int p = 0; p < ga.kp; ++p) {
+            const int dp = dp0 + p;
+            double kw = 0.0;
+            if (dp >= 0 && dp < W) {
+                const double *c = a.ktab + dp * (D + 1);
+                kw = c[D];
+#pragma unroll
+                for (int k = D - 1; k >= 0; --k) kw = fma(kw, z, c[k]);
+            }
+            pval[size_t(j) * size_t(ga.kp_alloc) + size_t(p)] = make_double2(val.x * kw, val.y * kw);
+        }
+    }
+}
+
 // pval_out != NULL (single-pass plans inside a Hessian apply): instead of accumulating the model visibility into sacc,
 // lane b < KP of the visibility's row writes it multiplied by the imaging weight and by the weight of plane b --
 // the input of k_grid_rec ((v * swgt) * kw, the products k_scale_sorted and the scatter would form).

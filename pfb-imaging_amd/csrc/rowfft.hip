@@ -470,11 +470,15 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
             continue;
         }
         // rows the groups request from (always valid memory: absent arrays alias the accumulator row and are dropped)
+        // (the FIN split of k_fused_fft_crop2 -- a lean instance for the planes that only update the running sum -- was tried
+        // here too: the 1024-thread shapes, 128 VGPRs, then spill 14-21 registers; one body stays)
         const size_t ro = size_t(y) * size_t(g.nx);
         const bool has_beam = finalize && fin.beam != nullptr, has_x = finalize && fin.x != nullptr;
         const double *crow = finalize ? fin.corr + ro : arow;
         const double *brow = has_beam ? fin.beam + ro : crow;
         const double *xrow = has_x ? fin.x + ro : crow;
+        // (a running sum that is not added is not read either: r03t's counters showed 0.54 GB per launch of it at C2)
+        const double *irow = add_img ? arow : crow;
         constexpr int GQ = 2;  // outputs per group (four: 64 VGPRs of requests in flight next to the 64 of the transform -- spills)
         constexpr int NG = S::E / GQ;
         double qi[2][GQ], qc[2][GQ], qb[2][GQ], qx[2][GQ];
@@ -482,7 +486,7 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_fft_crop(cons
 #pragma unroll
             for (int j = 0; j < GQ; ++j) {
                 const int ixc = max(fg_ix(g, S::out_pos(t, e0 + j)), 0);
-                qi[buf][j] = arow[ixc];
+                qi[buf][j] = irow[ixc];
                 qc[buf][j] = crow[ixc];
                 qb[buf][j] = brow[ixc];
                 qx[buf][j] = xrow[ixc];

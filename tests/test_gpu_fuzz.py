@@ -91,6 +91,40 @@ def test_fuzz_vs_dft(k):
     g.close()
 
 
+ES_CASES = [k for k in range(60) if CASES[k]["do_w"] and CASES[k]["wmode"] == 0][:25]
+
+
+@pytest.mark.parametrize("k", ES_CASES)
+def test_fuzz_record_scatter_on_es_plane_stacks(k, monkeypatch):
+    """PFBHIP_SCATTER=rec_es: the record scatter on ES-kernel plane stacks (values per pass from k_plane_values_es) -- an
+    option, k_grid_blk is the default there -- on the sweep's first ES-plane geometries, gridding direction against the DFT
+    and against the default kernel."""
+    from pfb_imaging_amd.wgridder import Gridder
+
+    p = CASES[k]
+    c = synth.make_case(p["nrow"], p["nchan"], max(p["nx"], p["ny"]), zscale=p["zscale"], seed=p["seed"])
+    cell = min(c["cell"] * p["widen"], 0.4 / max(p["nx"], p["ny"]))
+    fu, fv, fw = p["flips"]
+    cx, cy = p["center"]
+    nx, ny = p["nx"], p["ny"]
+    kw = dict(npix_x=nx, npix_y=ny, pixsize_x=cell, pixsize_y=cell * 1.1, center_x=cx, center_y=cy, epsilon=p["eps"], flip_u=fu,
+              flip_v=fv, flip_w=fw, do_wgridding=True, divide_by_n=p["divn"], force_wmode=0)
+    out = {}
+    for mode in ("rec_es", "block"):
+        monkeypatch.setenv("PFBHIP_SCATTER", mode)
+        g = Gridder(c["uvw"], c["freq"], c["mask"], **kw)
+        assert g.info["scatter_mode"] == (2 if mode == "rec_es" else 1), g.info
+        out[mode] = g.vis2dirty(c["vis"], c["wgt"])
+        g.close()
+    ref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], c["mask"], nx, ny, cell, cell * 1.1, cx, cy, fu, fv, fw, True,
+                            p["divn"])
+    if np.linalg.norm(ref) > 0:
+        assert rel(out["rec_es"], ref) < p["eps"], (p,)
+        # (the same sum in another order: rounding level, times the amplification of the image-edge correction on the wide
+        # fields of this sweep -- the three scatter forms differ by 7e-9 from one another at epsilon = 1e-5 there)
+        assert rel(out["rec_es"], out["block"]) < max(1e-9, 0.01 * p["eps"])
+
+
 def _midsize(seed, n):
     """Image sizes whose grids take the hand-written row FFT (fused second axis, transposing first axis, column runs,
     rectangle clear): the sweep of tools/soak_midsize.py."""

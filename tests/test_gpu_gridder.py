@@ -297,19 +297,23 @@ def test_scatter_forms_agree(eps, widen, zscale, monkeypatch):
     checked in test_binmap_bit_exact, which runs the default form)."""
     c = make(nrow=3000, npix=256, widen=widen, zscale=zscale)
     res = {}
-    for mode in ("block", "walk", "rec"):
+    for mode in ("block", "walk", "rec", "rec_es"):
         monkeypatch.setenv("PFBHIP_SCATTER", mode)
         g, kw, mask = gpu_plan(c, epsilon=eps)
-        # the record-driven form (k_grid_rec: per-visibility records, scalar loads) serves single-pass plans without
-        # ES-kernel w-planes; asked for elsewhere, the plan keeps k_grid_blk
+        # the record-driven form (k_grid_rec: per-visibility records, scalar loads) serves single-pass plans with polynomial
+        # w-planes; "rec_es" extends it to ES-kernel plane stacks (their values written per pass by k_plane_values_es: an
+        # option, not the default); asked for elsewhere, the plan keeps k_grid_blk
         single_pass = g.info["wmode"] == 1 and g.info["nplanes"] <= 4
-        assert g.info["scatter_mode"] == {"block": 1, "walk": 0, "rec": 2 if single_pass else 1}[mode], g.info
+        es = g.info["wmode"] == 0
+        assert g.info["scatter_mode"] == {"block": 1, "walk": 0, "rec": 2 if single_pass else 1,
+                                          "rec_es": 2 if (single_pass or es) else 1}[mode], g.info
         g.set_weights(c["wgt"])
         res[mode] = (g.vis2dirty(c["vis"], c["wgt"]), g.hessian(c["x"], eta=0.1, wsum=3.0), g.info["W"], g.info["nplanes"])
         g.close()
-    assert res["block"][2:] == res["walk"][2:] == res["rec"][2:]
+    assert res["block"][2:] == res["walk"][2:] == res["rec"][2:] == res["rec_es"][2:]
     assert rel(res["block"][0], res["walk"][0]) < 1e-9 and rel(res["block"][1], res["walk"][1]) < 1e-9
     assert rel(res["rec"][0], res["block"][0]) < 1e-9 and rel(res["rec"][1], res["block"][1]) < 1e-9
+    assert rel(res["rec_es"][0], res["block"][0]) < 1e-9 and rel(res["rec_es"][1], res["block"][1]) < 1e-9
     # left to itself the plan takes the single-launch walk kernel for a problem this small (a few hundred work items)
     monkeypatch.delenv("PFBHIP_SCATTER")
     g, kw, mask = gpu_plan(c, epsilon=eps)
