@@ -585,7 +585,7 @@ struct pfbhip_gridder {
                d_cfu.bytes() + d_cfv.bytes() + d_cheb.bytes() + d_ktab.bytes() + d_mask.bytes() + d_src.bytes() + d_work.bytes() + d_work_col.bytes() +
                d_grid.bytes() + d_grid2.bytes() + d_sval.bytes() + d_sacc.bytes() + d_vis.bytes() + d_wgt.bytes() + d_swgt.bytes() +
                d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes() + d_gridB.bytes() +
-               d_accT.bytes() + d_occ.bytes() + d_rowmap.bytes() + d_rec.bytes() + d_pval.bytes() + d_kw.bytes();
+               d_accT.bytes() + d_occ.bytes() + d_rowmap.bytes() + d_rec.bytes() + d_pval.bytes() + d_kw.bytes() + d_tau.bytes();
     }
 
     PlaneArgs plane_args(int plane) const
