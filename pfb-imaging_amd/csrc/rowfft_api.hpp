@@ -62,7 +62,7 @@ struct FusedFinal {
     double *out = nullptr;
 };
 constexpr int FUSED_MAXPLANES = 4;
-constexpr int FUSED_SCMAX = 8;  // coefficients of a composite screen polynomial (the kernels always evaluate all of them)
+constexpr int FUSED_SCMAX = 8;  // most coefficients a composite / residual screen polynomial may have (FusedPlanes::nsc of them are evaluated)
 struct FusedPlanes {
     int kp;
     double w[FUSED_MAXPLANES];  // w of each plane (wavelengths)
