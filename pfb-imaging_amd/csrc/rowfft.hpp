@@ -763,12 +763,12 @@ __device__ __forceinline__ void rf_for_each_load(int t, F &&f)
 }
 
 // The whole row: load -> passes -> store.
-template <class S, class Load, class Store>
+template <class S, class Load, class Store, int NB = S::LOAD_BATCH>
 __device__ __forceinline__ void rf_row(const double2 *__restrict__ tw, Load &ld, Store &st, bool inverse, double *lds)
 {
     double re[S::E], im[S::E];
     int t;
-    rf_row_compute<S>(tw, ld, inverse, lds, t, re, im);
+    rf_row_compute<S, Load, NB>(tw, ld, inverse, lds, t, re, im);
     rf_opaque(t);
     // No store before the last butterfly has consumed its twiddles: loads and stores share the in-order vmcnt, and behind
     // a (conditional) store the compiler waits vmcnt(0) for them -- i.e. for the store's own round trip to memory.
