@@ -38,6 +38,12 @@ int pfbhip_set_device(int device);
 int pfbhip_get_device(int *device);
 int pfbhip_device_name(char *buf, size_t buflen);
 int pfbhip_mem_info(size_t *free_bytes, size_t *total_bytes);
+/* Device blocks released by destroyed handles are kept for the next handle of the same sizes (hipMalloc costs ~45 ms per GB
+ * here; a plan is created per band and major cycle, as the reference creates its ducc0 plans per call,
+ * src/pfb_imaging/operators/gridder.py:590-613).  Reports the bytes currently cached (before the flush) and, with flush != 0,
+ * returns them to the driver.  PFBHIP_DEVCACHE_MB bounds the cache (default 131072, 0 = off); it empties itself when an
+ * allocation fails. */
+int pfbhip_device_cache(size_t *cached_bytes, int flush);
 /* replaces ducc0.misc.resize_thread_pool / thread_pool_size (src/pfb_imaging/operators/band_worker.py:50-52):
  * the "pool" is the GPU; kept so callers need no change. */
 int pfbhip_resize_thread_pool(int nthreads);

@@ -66,7 +66,7 @@ class CGInfo(ct.Structure):
 # every symbol include/pfbhip.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "pfbhip_last_error", "pfbhip_device_count", "pfbhip_set_device", "pfbhip_get_device", "pfbhip_device_name",
-    "pfbhip_mem_info", "pfbhip_resize_thread_pool", "pfbhip_thread_pool_size", "pfbhip_good_size",
+    "pfbhip_mem_info", "pfbhip_device_cache", "pfbhip_resize_thread_pool", "pfbhip_thread_pool_size", "pfbhip_good_size",
     "pfbhip_hash64", "pfbhip_host_alloc", "pfbhip_host_free", "pfbhip_malloc", "pfbhip_free", "pfbhip_memcpy_h2d", "pfbhip_memcpy_d2h", "pfbhip_memcpy_d2d", "pfbhip_memset",
     "pfbhip_synchronize",
     "pfbhip_gridder_create", "pfbhip_gridder_destroy", "pfbhip_gridder_get_info", "pfbhip_gridder_get_binmap",
@@ -130,6 +130,14 @@ def check(status):
 def device_count():
     n = cint(0)
     check(lib().pfbhip_device_count(ct.byref(n)))
+    return n.value
+
+
+def device_cache(flush=False):
+    """Bytes of released device blocks the library keeps for the next plan of the same sizes (``pfbhip_device_cache``);
+    ``flush=True`` returns them to the driver.  Returns the cached bytes before the flush."""
+    n = ct.c_size_t(0)
+    check(lib().pfbhip_device_cache(ct.byref(n), cint(1 if flush else 0)))
     return n.value
 
 

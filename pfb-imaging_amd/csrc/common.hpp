@@ -64,6 +64,17 @@ int guarded(F &&body) noexcept
     }
 }
 
+// Device allocations of the handles go through a process-wide cache of released blocks (runtime.cpp): hipMalloc costs
+// ~45 ms per GB on this platform (27 GB: 0.7-1.3 s; tools/malloc_probe.cpp) and a C5-size plan holds ~100 GB, so the second
+// plan of a geometry -- the next band, the next major cycle -- used to spend 5 s allocating what the first one had just
+// freed.  Blocks of >= 32 MiB are kept on release (exact-size reuse, per device, bounded by PFBHIP_DEVCACHE_MB, default
+// 131072; 0 disables) and everything cached is given back when an allocation fails.  Like hipFree, releasing a block waits for
+// the device first.  PFBHIP_DEVCACHE_POISON=1 fills every block handed out with 0xFF bytes (NaNs): no kernel may rely on
+// fresh memory being zero.
+void *dev_alloc(size_t bytes);
+void dev_free(void *p, size_t bytes) noexcept;
+size_t dev_cache_bytes(bool flush) noexcept;
+
 // Owning device buffer.
 template <class T>
 struct DevBuf {
@@ -83,7 +94,7 @@ struct DevBuf {
     void alloc(size_t count)
     {
         release();
-        if (count) PFB_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        if (count) p = static_cast<T *>(dev_alloc(count * sizeof(T)));
         n = count;
     }
     void ensure(size_t count)
@@ -92,7 +103,7 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) dev_free(p, n * sizeof(T));
         p = nullptr;
         n = 0;
     }

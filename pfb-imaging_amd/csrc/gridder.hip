@@ -1602,6 +1602,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             PFB_HIP(hipMemsetAsync(g->d_grid2.p, 0, g->d_grid2.bytes(), st));
         }
     }
+    lap("uv-plane buffers");
     g->d_img.alloc(size_t(npix));
     g->d_sval.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
     g->d_sacc.alloc(size_t(std::max<int64_t>(info.nactive, 1)));
@@ -1717,8 +1718,10 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             g->fgeom.tpitch = int(prm.ny) + ((tpad + 7) / 8) * 8;
     }
     g->bstride = std::max(g->bstride, size_t(info.nu) * size_t(g->fgeom.tpitch));
+    lap("row-FFT tables + w-screens");
     g->d_gridB.alloc(g->bstride * size_t(g->fused ? g->kp_max : 1));
     g->d_accT.alloc(size_t(npix));
+    lap("intermediate plane + image buffers");
 
     // occupancy of 32-row blocks of the uv-plane: tile rows that hold work, plus the block their
     // (W-1)-cell halo spills into
@@ -1732,17 +1735,41 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         for (int64_t r = tu * TILE; r <= tu * TILE + TILE + info.W - 2; ++r) occ[size_t((r % info.nu) / TP)] = 1;
     }
     bool colruns_off = false;
+    // tiles a footprint cell of some work item can fall in (the item's own tile and the tiles its (W - 1)-cell halo reaches,
+    // wrapped; through a short last tile if the grid size is not a multiple of TILE).  Per TILE with work, and per row /
+    // column of its region rather than per cell: the per-cell, per-item form of this loop was 0.1 s of the 0.13 s a C2 plan
+    // takes and 3.1 s of C5's 3.3 (18 449 / 400 000 work items x 47^2 cells x two passes).
+    std::vector<uint8_t> touched_tiles;
+    if (!work.empty()) {
+        const int64_t ntu_t = ceil_div(info.nu, TILE), ntv_t = m.ntv;
+        touched_tiles.assign(size_t(ntu_t * ntv_t), 0);
+        std::vector<uint8_t> seen(size_t(info.ntiles), 0);
+        for (const WorkItem &wi : work) {
+            if (seen[wi.tile]) continue;
+            seen[wi.tile] = 1;
+            const int64_t tu = wi.tile / uint32_t(m.ntv), tv = wi.tile % uint32_t(m.ntv);
+            constexpr int MAXT = 8;  // (own tile, short last tile, tile 0, ...: four on the smallest grids)
+            int64_t tr[MAXT], tc[MAXT];
+            int ntr = 0, ntc = 0;
+            for (int64_t r = tu * TILE; r <= tu * TILE + TILE + info.W - 2; ++r) {
+                const int64_t t = (r % info.nu) / TILE;
+                if (ntr == 0 || (tr[ntr - 1] != t && ntr < MAXT)) tr[ntr++] = t;
+                PFB_REQUIRE(tr[ntr - 1] == t, "tile rows of a footprint region");
+            }
+            for (int64_t q = tv * TILE; q <= tv * TILE + TILE + info.W - 2; ++q) {
+                const int64_t t = (q % info.nv) / TILE;
+                if (ntc == 0 || (tc[ntc - 1] != t && ntc < MAXT)) tc[ntc++] = t;
+                PFB_REQUIRE(tc[ntc - 1] == t, "tile columns of a footprint region");
+            }
+            for (int a = 0; a < ntr; ++a)
+                for (int b = 0; b < ntc; ++b) touched_tiles[size_t(tr[a] * ntv_t + tc[b])] = 1;
+        }
+    }
     {   // column runs per tile row (default: the whole row)
         const int64_t ntu_t = ceil_div(info.nu, TILE), ntv_t = m.ntv;
         std::vector<int4> runs_t(size_t(ntu_t), make_int4(0, int(info.nv), 0, 0));
         if (!work.empty()) {
-            std::vector<uint8_t> touched(size_t(ntu_t * ntv_t), 0);
-            for (const WorkItem &wi : work) {
-                const int64_t tu = wi.tile / uint32_t(m.ntv), tv = wi.tile % uint32_t(m.ntv);
-                for (int64_t r = tu * TILE; r <= tu * TILE + TILE + info.W - 2; ++r)
-                    for (int64_t q = tv * TILE; q <= tv * TILE + TILE + info.W - 2; ++q)
-                        touched[size_t(((r % info.nu) / TILE) * ntv_t + (q % info.nv) / TILE)] = 1;
-            }
+            const std::vector<uint8_t> &touched = touched_tiles;
             for (int64_t tu = 0; tu < ntu_t; ++tu) {
                 std::vector<std::pair<int, int>> rr;
                 for (int64_t tv = 0; tv < ntv_t;) {
@@ -1775,13 +1802,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     }
     if (!work.empty() && !colruns_off) {  // (side-stream clear of single-pass plans; clear_planes() on the transposing path)
         const int64_t ntu_t = ceil_div(info.nu, TILE), ntv_t = m.ntv;
-        std::vector<uint8_t> touched(size_t(ntu_t * ntv_t), 0);
-        for (const WorkItem &wi : work) {
-            const int64_t tu = wi.tile / uint32_t(m.ntv), tv = wi.tile % uint32_t(m.ntv);
-            for (int64_t r = tu * TILE; r <= tu * TILE + TILE + info.W - 2; ++r)  // every tile a footprint cell can fall in
-                for (int64_t q = tv * TILE; q <= tv * TILE + TILE + info.W - 2; ++q)
-                    touched[size_t(((r % info.nu) / TILE) * ntv_t + (q % info.nv) / TILE)] = 1;
-        }
+        const std::vector<uint8_t> &touched = touched_tiles;
         std::vector<int4> rects;
         int64_t cells = 0, full = 0;
         constexpr int SLICE = 8;  // rows per rectangle: enough workgroups to fill the chip
@@ -1894,6 +1915,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         if (!g->tfft) g->n_clear_rects = 0;  // (the plain first-axis transform runs IN PLACE on the scatter's planes: whole rows to clear)
         info.fft_mode |= g->tfft ? 8 : 0;
     }
+    lap("occupancy, column runs, row map");
     if (any_rocfft) {
         PFB_ROCFFT(rocfft_execution_info_create(&g->fft_info));
         if (wmax) {
@@ -1905,7 +1927,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     // rows of A outside the occupied spans are never written: clear the plane once
     PFB_HIP(hipMemsetAsync(g->d_grid.p, 0, g->d_grid.bytes(), st));
     PFB_HIP(hipStreamSynchronize(st));
-    lap("buffers + FFT plans");
+    lap("rocFFT plans + plane clear");
     info.device_bytes = g->device_bytes();
 }
 

@@ -4,7 +4,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -67,6 +69,102 @@ void allow_dynamic_lds(const void *kernel, int bytes)
 
 }  // namespace pfbhip
 
+// ---- cache of released device blocks (see common.hpp) ----
+namespace pfbhip {
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void *> blocks;  // (device, bytes) -> block
+    size_t cached = 0;
+    size_t limit = size_t(131072) << 20;
+    bool poison = false;
+    static constexpr size_t MIN_BLOCK = size_t(32) << 20;
+    DevCache()
+    {
+        if (const char *e = std::getenv("PFBHIP_DEVCACHE_MB")) limit = size_t(std::max(0ll, std::atoll(e))) << 20;
+        if (const char *e = std::getenv("PFBHIP_DEVCACHE_POISON")) poison = e[0] == '1';
+    }
+    // (never destroyed: blocks still cached at process exit go with the context)
+};
+DevCache &dev_cache()
+{
+    static DevCache *c = new DevCache();
+    return *c;
+}
+}  // namespace
+
+size_t dev_cache_bytes(bool flush) noexcept
+{
+    DevCache &c = dev_cache();
+    std::vector<void *> drop;
+    size_t was;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        was = c.cached;
+        if (flush) {
+            for (auto &kv : c.blocks) drop.push_back(kv.second);
+            c.blocks.clear();
+            c.cached = 0;
+        }
+    }
+    for (void *p : drop) (void)hipFree(p);
+    return was;
+}
+
+void *dev_alloc(size_t bytes)
+{
+    DevCache &c = dev_cache();
+    void *p = nullptr;
+    int dev = 0;
+    PFB_HIP(hipGetDevice(&dev));
+    if (bytes >= DevCache::MIN_BLOCK && c.limit > 0) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.blocks.find(std::make_pair(dev, bytes));
+        if (it != c.blocks.end()) {
+            p = it->second;
+            c.blocks.erase(it);
+            c.cached -= bytes;
+        }
+    }
+    if (p == nullptr) {
+        hipError_t err = hipMalloc(&p, bytes);
+        if (err == hipErrorOutOfMemory) {  // give back what the cache holds and try once more
+            (void)hipGetLastError();
+            (void)dev_cache_bytes(true);
+            err = hipMalloc(&p, bytes);
+        }
+        PFB_HIP(err);
+    }
+    if (c.poison) {
+        PFB_HIP(hipMemset(p, 0xFF, bytes));
+        PFB_HIP(hipDeviceSynchronize());
+    }
+    return p;
+}
+
+void dev_free(void *p, size_t bytes) noexcept
+{
+    if (p == nullptr) return;
+    DevCache &c = dev_cache();
+    int dev = 0;
+    if (bytes >= DevCache::MIN_BLOCK && c.limit > 0 && hipGetDevice(&dev) == hipSuccess) {
+        hipPointerAttribute_t attr;
+        // a block goes back to the cache of the device it lives on; like hipFree, not before the device is done with it
+        if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.device == dev && hipDeviceSynchronize() == hipSuccess) {
+            std::lock_guard<std::mutex> lk(c.mu);
+            if (c.cached + bytes <= c.limit) {
+                c.blocks.emplace(std::make_pair(dev, bytes), p);
+                c.cached += bytes;
+                return;
+            }
+        }
+        (void)hipGetLastError();
+    }
+    (void)hipFree(p);
+}
+}  // namespace pfbhip
+
+
 using namespace pfbhip;
 
 extern "C" {
@@ -111,6 +209,14 @@ int pfbhip_device_name(char *buf, size_t buflen)
         std::string s = std::string(prop.name) + " (" + prop.gcnArchName + ")";
         std::strncpy(buf, s.c_str(), buflen - 1);
         buf[buflen - 1] = 0;
+    });
+}
+
+int pfbhip_device_cache(size_t *cached_bytes, int flush)
+{
+    return guarded([&] {
+        const size_t was = pfbhip::dev_cache_bytes(flush != 0);
+        if (cached_bytes) *cached_bytes = was;
     });
 }
 

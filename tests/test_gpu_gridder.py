@@ -531,6 +531,36 @@ def test_doubled_fft_shapes_vs_oracle(nx, ny, monkeypatch):
     assert rel(d1, d) < 1e-11 and rel(v1, v) < 1e-11 and rel(h1, h) < 1e-11
 
 
+def test_device_block_cache_reuse_and_flush():
+    """Device blocks of a destroyed plan wait in the library's cache for the next plan of the same sizes (hipMalloc costs
+    ~45 ms per GB; csrc/common.hpp dev_alloc): the second plan takes them back out, computes the same image from recycled
+    (not zeroed) memory, and a flush returns everything to the driver."""
+    from pfb_imaging_amd import _lib
+
+    c = make(nrow=2000, npix=64, widen=8.0)
+    rng = np.random.default_rng(21)
+    c["nx"] = c["ny"] = 1100
+    c["cell"] = c["cell"] * 64.0 / 1100
+    c["x"] = rng.standard_normal((1100, 1100))
+    _lib.device_cache(flush=True)
+    assert _lib.device_cache() == 0
+    g, kw, mask = gpu_plan(c)
+    d1 = g.vis2dirty(c["vis"], c["wgt"])
+    v1 = g.dirty2vis(c["x"])
+    held = g.info["device_bytes"]
+    g.close()
+    cached = _lib.device_cache()
+    assert 0 < cached <= held, (cached, held)      # (blocks below 32 MiB are not kept)
+    g2, _, _ = gpu_plan(c)
+    assert _lib.device_cache() < cached            # the new plan took blocks of the old one
+    d2 = g2.vis2dirty(c["vis"], c["wgt"])
+    v2 = g2.dirty2vis(c["x"])
+    assert rel(d2, d1) < 1e-12 and rel(v2, v1) < 1e-12
+    g2.close()
+    assert _lib.device_cache(flush=True) >= cached
+    assert _lib.device_cache() == 0
+
+
 def test_separable_screen_matches_general_form(monkeypatch):
     """The w-screen of a pass in separable form (per-plane column table x row factor x residual polynomials,
     csrc/rowfft_api.hpp FusedPlanes::sep) against the same plan with n - 1 and sincos per pixel (PFBHIP_SEPSCREEN=0),
