@@ -332,7 +332,15 @@ int pfbhip_malloc(void **ptr_dev, size_t bytes)
     return guarded([&] {
         PFB_REQUIRE(ptr_dev, "NULL argument");
         *ptr_dev = nullptr;
-        if (bytes) PFB_HIP(hipMalloc(ptr_dev, bytes));
+        if (bytes) {
+            hipError_t err = hipMalloc(ptr_dev, bytes);
+            if (err == hipErrorOutOfMemory) {  // the handles' block cache gives way to the caller's buffers
+                (void)hipGetLastError();
+                (void)pfbhip::dev_cache_bytes(true);
+                err = hipMalloc(ptr_dev, bytes);
+            }
+            PFB_HIP(err);
+        }
     });
 }
 
