@@ -333,8 +333,17 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
     const uint32_t j1 = wi.begin + uint32_t((uint64_t(n) * uint32_t(wave + 1)) / NW);
     uint32_t jl = j0 + uint32_t(lane);
     bool lvalid = jl < j1;
-    double npu = lvalid ? a.pu[jl] : 0.0, npv = lvalid ? a.pv[jl] : 0.0, npw = (lvalid && a.do_w) ? a.pw[jl] : 0.0;
-    double2 nval = lvalid ? sval[jl] : make_double2(0.0, 0.0);
+    double npu, npv, npw;
+    double2 nval;
+    {
+        const uint32_t jc = lvalid ? jl : wi.begin;
+        const double qu = a.pu[jc], qv = a.pv[jc], qw = a.pw[jc]  /* (always allocated; dropped below without w-gridding) */;
+        const double2 qs = sval[jc];
+        npu = lvalid ? qu : 0.0;
+        npv = lvalid ? qv : 0.0;
+        npw = (lvalid && a.do_w) ? qw : 0.0;
+        nval = lvalid ? qs : make_double2(0.0, 0.0);
+    }
     for (int i = threadIdx.x; i < 2 * KP * LL; i += BLK_THREADS) lds[i] = 0.0;
     for (int i = threadIdx.x; i < W * (D + 1); i += BLK_THREADS) wtab[i] = a.ktab[i];
     for (int i = threadIdx.x; i < (BLK_THREADS / 64) * 2 * BLK_SCRATCH; i += BLK_THREADS) scr_all[i] = 0.0;
@@ -394,10 +403,18 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
         const bool valid = lvalid;
         jl += 64;
         lvalid = jl < j1;
-        npu = lvalid ? a.pu[jl] : 0.0;
-        npv = lvalid ? a.pv[jl] : 0.0;
-        npw = (lvalid && a.do_w) ? a.pw[jl] : 0.0;
-        nval = lvalid ? sval[jl] : make_double2(0.0, 0.0);
+        {
+            // the next batch's requests, branch-free from a clamped index (round 3: `lvalid ? a.pu[jl] : 0` compiled to a branch
+            // around each load with s_waitcnt vmcnt(0) at the join -- the "prefetch" was waited for on the spot, one memory
+            // round trip per 64 visibilities.  Measured neutral, C5 grid 195 -> 196 ms: the other waves cover it)
+            const uint32_t jc = lvalid ? jl : wi.begin;  // (work items are not empty: a valid index)
+            const double qu = a.pu[jc], qv = a.pv[jc], qw = a.pw[jc]  /* (always allocated; dropped below without w-gridding) */;
+            const double2 qs = sval[jc];
+            npu = lvalid ? qu : 0.0;
+            npv = lvalid ? qv : 0.0;
+            npw = (lvalid && a.do_w) ? qw : 0.0;
+            nval = lvalid ? qs : make_double2(0.0, 0.0);
+        }
         // per lane = per visibility of the batch
         const double fu = floor(pu + shift), fv = floor(pv + shift);
         const double zuv = 2.0 * ((pu + shift) - fu) - 1.0, zvv = 2.0 * ((pv + shift) - fv) - 1.0;
@@ -1114,7 +1131,22 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
     const uint32_t stride = (MP_THREADS / 64) * 4;
     uint32_t j = wi.begin + wave * 4 + g;
     bool valid = j < wi.end;
-    double pu = valid ? a.pu[j] : 0.0, pv = valid ? a.pv[j] : 0.0, pw = (valid && a.do_w) ? a.pw[j] : 0.0;
+    // (requests branch-free from a clamped index, round 3: `valid ? a.pu[j] : 0` is a branch around each load with a
+    // s_waitcnt vmcnt(0) at the join -- the next round's "prefetch" below was waited for on the spot; the running sum of the
+    // multi-pass accumulation travels with it instead of being read, waited for and written at the end of every round.
+    // Measured neutral: C5 degrid 107 -> 108 ms)
+    const bool rmw = pval_out == nullptr;
+    const double2 *accp = rmw ? sacc : grid;  // (always a valid address: the plane-value form does not read the running sum)
+    double pu, pv, pw;
+    double2 acc0;
+    {
+        const uint32_t jc = valid ? j : wi.begin;
+        const double qu = a.pu[jc], qv = a.pv[jc], qw = a.pw[jc]  /* (always allocated; dropped below without w-gridding) */;
+        acc0 = accp[rmw ? jc : 0u];
+        pu = valid ? qu : 0.0;
+        pv = valid ? qv : 0.0;
+        pw = (valid && a.do_w) ? qw : 0.0;
+    }
     {
         // every load of the thread's cells (all planes) in flight before the first LDS store: a load -> store chain per
         // cell exposes the HBM latency once per cell and plane
@@ -1158,8 +1190,10 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
     for (uint32_t jb = wi.begin + wave * 4; jb < wi.end; jb += stride) {
         const uint32_t jn = j + stride;
         const bool nvalid = jn < wi.end;
-        const double npu = nvalid ? a.pu[jn] : 0.0, npv = nvalid ? a.pv[jn] : 0.0;
-        const double npw = (nvalid && a.do_w) ? a.pw[jn] : 0.0;
+        const uint32_t jc = nvalid ? jn : wi.begin;
+        const double qu = a.pu[jc], qv = a.pv[jc], qw = a.pw[jc]  /* (always allocated; dropped below without w-gridding) */;
+        const double2 nacc = accp[rmw ? jc : 0u];
+        const double npu = nvalid ? qu : 0.0, npv = nvalid ? qv : 0.0, npw = (nvalid && a.do_w) ? qw : 0.0;
         {
             double kwl = (b < kp && valid) ? plane_weight_of<W, D>(a, a.plane + b, mycoef, pw, wtab) : 0.0;
             const double fu = floor(pu + shift), fv = floor(pv + shift);
@@ -1252,13 +1286,11 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_mp(GroupArgs ga, const do
                     pval_out[size_t(j) * size_t(ga.kp_alloc) + size_t(b)] = make_double2((tr * wj) * kwl, (ti * wj) * kwl);
                 }
             } else if (b == 0 && touch) {
-                double2 acc = sacc[j];
-                acc.x += tr;
-                acc.y += ti;
-                sacc[j] = acc;
+                sacc[j] = make_double2(acc0.x + tr, acc0.y + ti);
             }
         }
         j = jn;
+        acc0 = nacc;
         valid = nvalid;
         pu = npu;
         pv = npv;
