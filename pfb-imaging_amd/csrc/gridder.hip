@@ -1122,6 +1122,7 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
         // Candidate grids: the smallest 2-3-5-7-smooth size >= sigma n, and the smallest size the
         // hand-written row FFT supports ({1,3,5} x 2^a) if that stays within sigma_max -- a larger grid
         // with the same (W, beta) only lowers the aliasing error.
+        double rounding_es = 0.0, rounding_poly = 0.0;
         int64_t cand_u[2] = {grid_size(prm.nx, r.sigma), rowfft_size_at_least(double(prm.nx) * r.sigma)};
         int64_t cand_v[2] = {grid_size(prm.ny, r.sigma), rowfft_size_at_least(double(prm.ny) * r.sigma)};
         for (int cand = 0; cand < 2; ++cand) {
@@ -1131,10 +1132,28 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
             if (cand == 1 && prm.force_W <= 0 &&
                 (double(nu) > prm.sigma_max * double(prm.nx) || double(nv) > prm.sigma_max * double(prm.ny)))
                 continue;
+            // Rounding, the third term of the error budget (round 3; found by tools/soak_midsize.py 5, case 13): the image-side
+            // correction 1 / psi amplifies the rounding errors of the grid and of the FFT, at the image corner by
+            // psi(0)^2 / (psi(x_edge) psi(y_edge)), times psi(0) / psi(0.5 / sigma) of the w-kernel for ES-kernel planes.  A W = 16
+            // row at sigma = 1.15 under an image that fills its grid (n / nu = 0.86) reaches 1.6e12 there, and the relative L2
+            // error of the image was 4e-7 of pure rounding at epsilon = 1e-6 (2.5e-19 x the corner amplification, measured).
+            // Rows whose rounding share would pass 0.2 epsilon are not admissible; the wider grids (sigma >= 1.25) every
+            // epsilon <= 3e-7 needs stay below 1e-8.
+            if (prm.force_W <= 0) {
+                const KernelFT ft(r.W, r.beta);
+                const double f0 = ft(0.0);
+                double amp = (f0 / ft(0.5 * double(prm.nx) / double(nu))) * (f0 / ft(0.5 * double(prm.ny) / double(nv)));
+                if (wgrid) amp = std::max(amp, amp * f0 / ft(0.5 / r.sigma));  // (ES-kernel planes; the polynomial scheme has none)
+                rounding_es = 2.5e-19 * amp;
+                rounding_poly = rounding_es * ft(0.5 / r.sigma) / f0;
+            } else {
+                rounding_es = rounding_poly = 0.0;
+            }
             RowFFTPlan tmp;
             const bool own = rowfft_make_plan(nu, &tmp) && rowfft_make_plan(nv, &tmp);
             for (int mode = 0; mode < (wgrid ? 2 : 1); ++mode) {
                 if (wgrid && prm.force_wmode != 0 && prm.force_wmode != mode + 1) continue;
+                if ((wgrid && mode == 0 ? rounding_es : (wgrid ? rounding_poly : rounding_es)) > 0.2 * prm.epsilon) continue;
                 double dw = 1.0;
                 int64_t npl = 1, touched = 1;
                 if (wgrid) {
