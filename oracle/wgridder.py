@@ -228,8 +228,15 @@ def choose_params(uvw, freq, mask, nx, ny, px, py, center_x, center_y, epsilon, 
             if r["sigma"] < sigma_min - 1e-9 or r["sigma"] > sigma_max + 1e-9 or r.get("eps_sup", r["eps_max"]) > eps1:
                 continue
         nu, nv = grid_size(nx, r["sigma"]), grid_size(ny, r["sigma"])
+        # (rounding amplified by the image-side correction: the product's third budget term, see choose_kernel)
+        f0 = float(kernel_ft(np.array([0.0]), r["W"], r["beta"])[0])
+        amp2 = (f0 / float(kernel_ft(np.array([0.5 * nx / nu]), r["W"], r["beta"])[0])) * \
+               (f0 / float(kernel_ft(np.array([0.5 * ny / nv]), r["W"], r["beta"])[0]))
+        ampw = f0 / float(kernel_ft(np.array([0.5 / r["sigma"]]), r["W"], r["beta"])[0])
         for wmode in ((0, 1) if (do_wgridding and tmax > 0 and force_wmode is None) else
                       ((force_wmode,) if (do_wgridding and tmax > 0) else (0,))):
+            if force is None and 2.5e-19 * amp2 * (max(ampw, 1.0) if (do_wgridding and tmax > 0 and wmode == 0) else 1.0) > 0.2 * epsilon:
+                continue
             if do_wgridding and tmax > 0:
                 if wmode == 0:
                     dw = 0.5 / r["sigma"] / tmax
