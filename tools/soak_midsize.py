@@ -38,7 +38,10 @@ for k in range(ncases):
     refv = dft.dft_dirty2vis(c["uvw"][rows], c["freq"], x, cell, cell * 1.07, cx, cy, fu, fv, fw, do_w, divn)
     refv[c["mask"][rows] == 0] = 0
     e.append(rel(v[rows], refv) / eps)
-    ok = e[0] < 3e-8 and e[1] < 3e-8 and e[2] < 2e-8 and e[3] < 1e-9 and e[4] < 1.0  # (vs the restatement: FFT rounding x the edge correction, up to ~1e8)  # (e[3]: run-to-run, LDS atomics reorder sums)
+    # vs the restatement: FFT rounding x the image-side correction -- the plan admits up to 0.2 epsilon of it (choose_kernel);
+    # e[3]: run-to-run, LDS atomics reorder sums (the same rounding, an order of magnitude lower)
+    lim = max(3e-8, 0.2 * eps)
+    ok = e[0] < lim and e[1] < lim and e[2] < lim and e[3] < max(1e-9, 0.02 * eps) and e[4] < 1.0
     bad += not ok
     print(k, "OK " if ok else "BAD", (nx, ny), {q: g.info[q] for q in ("nu", "nv", "nplanes", "W", "wmode", "fft_mode", "scatter_mode", "used_cells")},
           dict(eps=eps, flips=(fu, fv, fw), center=(cx, cy), do_w=do_w, divn=divn), ["%.1e" % q for q in e], flush=True)
