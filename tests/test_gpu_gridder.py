@@ -280,7 +280,7 @@ def test_gridder_cg_matches_oracle_pcg():
     g, gkw, mask = gpu_plan(c)
     g.set_weights(c["wgt"])
     wsum = c["wgt"][mask != 0].sum()
-    eta = 0.1
+    eta = 0.5  # (the CPU restatement's solve is what this test's time goes into: a better-conditioned system, fewer iterations)
     rhs = g.hessian(c["x"], eta=eta, wsum=wsum)
     sol = g.cg(rhs, eta=eta, wsum=wsum, tol=1e-9, maxit=200, minit=1)
     assert rel(sol, c["x"]) < 1e-6
@@ -327,20 +327,20 @@ def test_gridder_power_method_matches_oracle():
     from oracle.fftconv import power_method as pm_oracle
     from pfb_imaging_amd.opt import power_method
 
-    c = make(nrow=2500, npix=32, widen=20.0)
+    c = make(nrow=900, npix=32, widen=20.0)
     g, gkw, mask = gpu_plan(c)
     g.set_weights(c["wgt"])
     wsum = c["wgt"][mask != 0].sum()
     b0 = np.random.default_rng(8).standard_normal((c["nx"], c["ny"]))
     o = oracle_plan(c, g, gkw, mask)
     rbeta, rb, rk = pm_oracle(lambda z: o.vis2dirty(o.dirty2vis(z), c["wgt"]) / wsum + 0.1 * z, b0.shape, b0.copy(), tol=0.0,
-                              maxit=15)
-    beta, b = g.power_method(b0, eta=0.1, wsum=wsum, tol=0.0, maxit=15)
-    assert g.last_pm["iters"] == 15 == rk
+                              maxit=6)
+    beta, b = g.power_method(b0, eta=0.1, wsum=wsum, tol=0.0, maxit=6)
+    assert g.last_pm["iters"] == 6 == rk
     assert abs(beta - rbeta) < 1e-8 * rbeta and rel(b, rb) < 1e-6
     # the reference's call form; eta = 0, wsum = 1 are Gridder.hessian's defaults
-    beta2, b2 = power_method(g.hessian, b0.shape, b0=b0, tol=0.0, maxit=15, verbosity=0)
-    rbeta2, rb2, _ = pm_oracle(lambda z: o.vis2dirty(o.dirty2vis(z), c["wgt"]), b0.shape, b0.copy(), tol=0.0, maxit=15)
+    beta2, b2 = power_method(g.hessian, b0.shape, b0=b0, tol=0.0, maxit=6, verbosity=0)
+    rbeta2, rb2, _ = pm_oracle(lambda z: o.vis2dirty(o.dirty2vis(z), c["wgt"]), b0.shape, b0.copy(), tol=0.0, maxit=6)
     assert abs(beta2 - rbeta2) < 1e-8 * rbeta2 and rel(b2, rb2) < 1e-6
     g.close()
 
