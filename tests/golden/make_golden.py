@@ -7,10 +7,8 @@ be imported here.  These fixtures are therefore produced by this repository's ow
 direct-DFT oracle (oracle/dft.py) on the *inputs* the reference's tests construct; nothing is
 imported from /root/reference.
 
-  conventions_two_sources.npz   inputs + expected visibilities of test_wgridder_conventions
-                                (/root/reference/tests/test_hessian_approx.py:128-185: seed 42,
-                                100 antennas, 2 freqs 700-2000 MHz, npix 1024, 0.5" cells, two unit
-                                point sources, five centre offsets, divide_by_n=True)
+  (conventions_two_sources.npz and ref_pins.npz are NOT made here: they hold outputs of the reference's own
+   functions, see make_ref_pins.py)
   synth_partition.npz           _synth_partition(nrow=200, seed=0) of
                                 /root/reference/tests/test_imager_pass2.py:10-29 with DFT dirty (16^2)
                                 and PSF (32^2) under wgridder_conventions(0, 0)
@@ -22,7 +20,6 @@ imported from /root/reference.
 Run from the repo root:  python tests/golden/make_golden.py
 """
 
-import itertools
 import os
 import sys
 
@@ -33,27 +30,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import dft  # noqa: E402
 from pfb_imaging_amd.utils import synth  # noqa: E402
-
-
-def conventions():
-    np.random.seed(42)
-    npix, num_ants, num_freqs = 1024, 100, 2
-    pixsize = 0.5 * np.pi / 180 / 3600.0
-    a1, a2 = np.asarray(list(itertools.combinations(range(num_ants), 2))).T
-    ant = 10e3 * np.random.normal(size=(num_ants, 3))
-    ant[:, 2] *= 0.001
-    uvw = ant[a1] - ant[a2]
-    freqs = np.linspace(700e6, 2000e6, num_freqs)
-    offsets = np.array([(0.0, 0.0), (0.1, -0.17), (0.2, 0.5), (-0.1, 0.2), (-0.15, -0.2)])
-    dirty = np.zeros((npix, npix))
-    dirty[npix // 2, npix // 2] = 1.0
-    dirty[npix // 4, npix // 4] = 1.0
-    vis = []
-    for l0, m0 in offsets:
-        # wgridder_conventions(l0, m0) = (False, True, False, -l0, -m0)
-        vis.append(dft.dft_dirty2vis(uvw, freqs, dirty, pixsize, pixsize, -l0, -m0, False, True, False, True, True))
-    np.savez_compressed(os.path.join(HERE, "conventions_two_sources.npz"), uvw=uvw, freq=freqs, npix=npix,
-                        pixsize=pixsize, offsets=offsets, vis=np.array(vis))
 
 
 def synth_partition():
@@ -98,7 +74,6 @@ def wstack_small():
 
 
 if __name__ == "__main__":
-    conventions()
     synth_partition()
     uv2xy()
     wstack_small()

@@ -226,3 +226,114 @@ def test_psi_oracle_pins():
         xb = np.zeros_like(x)
         P.hdot(b, xb)
         assert abs(np.vdot(a, b) - np.vdot(x, xb)) < 1e-10 * abs(np.vdot(x, xb))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Reference-RUN fixtures (tests/golden/ref_pins.npz, conventions_two_sources.npz): outputs of the reference's own
+# undecorated numpy / scipy functions, executed by tests/golden/make_ref_pins.py in the build container.  These
+# tests need neither /root/reference nor a GPU.
+# ---------------------------------------------------------------------------------------------------------
+
+def test_oracle_vs_reference_run_fixtures(golden_dir):
+    """oracle/dft.py, oracle/psi.py (prox_21m, dual_update), oracle/weighting.py (filter / box sum), oracle/fftconv.py
+    (taperf, power_method) reproduce what the REFERENCE's functions returned on the same inputs.
+
+    Tolerances: 1e-12 (absolute, on O(1) values) wherever the arithmetic is well conditioned; the two-point-source
+    visibilities of the reference's own test geometry carry phases of ~1e6 rad, whose f64 rounding alone is 1e-10, so
+    that case is held to 2e-9 (the reference's own test holds ducc0 to 1e-4 there)."""
+    pins = np.load(f"{golden_dir}/ref_pins.npz")
+    conv = np.load(f"{golden_dir}/conventions_two_sources.npz")
+    assert "reference" in str(conv["source"])
+
+    # -- measurement equation: the reference's test geometry, all five offsets, both conventions ------------------
+    uvw, freq, npix, pix = conv["uvw"], conv["freq"], int(conv["npix"]), float(conv["pixsize"])
+    dirty = np.zeros((npix, npix))
+    dirty[npix // 2, npix // 2] = 1.0
+    dirty[npix // 4, npix // 4] = 1.0
+    for k, (l0, m0) in enumerate(conv["offsets"]):
+        # explicit_wdegridder (flip_v = True, centre = wgridder_conventions(l0, m0))
+        v = dft.dft_dirty2vis(uvw, freq, dirty, pix, pix, -l0, -m0, False, True, False, True, True)
+        assert np.abs(v - conv["vis"][k]).max() < 2e-9
+        # explicit_degridder, "casa" convention = ducc0's defaults (no flips), centre (-l0, -m0)
+        v = dft.dft_dirty2vis(uvw, freq, dirty, pix, pix, -l0, -m0, False, False, False, True, True)
+        assert np.abs(v - conv["vis_casa"][k]).max() < 2e-9
+        assert np.abs(v - conv["vis_casa_negw"][k]).max() < 2e-9
+
+    # -- the same on a dense, well-conditioned wide-field case: every pixel, 1e-12 ---------------------------------
+    px, py = pins["dense_pix"]
+    img = pins["dense_img"]
+    for k, (l0, m0) in enumerate(pins["conv_lm"][:3]):
+        v = dft.dft_dirty2vis(pins["dense_uvw"], pins["dense_freq"], img, px, py, -l0, -m0, False, True, False, True, True)
+        assert np.abs(v - pins["dense_vis_w"][k]).max() < 1e-12 * np.abs(pins["dense_vis_w"][k]).max()
+        v = dft.dft_dirty2vis(pins["dense_uvw"], pins["dense_freq"], img, px, py, -l0, -m0, False, False, False, True, True)
+        assert np.abs(v - pins["dense_vis_casa"][k]).max() < 1e-12 * np.abs(pins["dense_vis_casa"][k]).max()
+        # and the adjoint the oracle defines from it: <R x, y> == <x, R^H y> ties dft_vis2dirty to the pinned direction
+        y = pins["dense_vis_w"][k]
+        d = dft.dft_vis2dirty(pins["dense_uvw"], pins["dense_freq"], y, None, None, img.shape[0], img.shape[1], px, py,
+                              -l0, -m0, False, True, False, True, True)
+        lhs = np.vdot(pins["dense_vis_w"][k], y).real
+        assert abs(np.vdot(img, d) - lhs) < 1e-11 * abs(lhs)
+
+    # -- l21 prox / dual update ------------------------------------------------------------------------------------
+    from oracle import psi as opsi
+
+    for i in range(3):
+        v, w, s = pins[f"prox{i}_v"], pins[f"prox{i}_w"], float(pins[f"prox{i}_sigma"])
+        assert np.abs(opsi.prox_21m(v, s, weight=w) - pins[f"prox{i}_out"]).max() < 1e-12
+        assert np.abs(opsi.prox_21m(v, s) - pins[f"prox{i}_out_w1"]).max() < 1e-12
+    # dual_update (allocating form, prox_21m.py:64-71) == the fused in-place form the oracle restates
+    # (dual_update_numba_fast, :105-135) given the analysis coefficients of x
+    q, x = pins["du_q"], pins["du_x"]
+    coeffs = np.stack([x, np.einsum("ij,bjk->bik", q, x)], axis=1)
+    got = opsi.dual_update(pins["du_v"].copy(), coeffs, float(pins["du_lam"]), float(pins["du_sigma"]), pins["du_w"])
+    assert np.abs(got - pins["du_out"]).max() < 1e-12
+
+    # -- counts filters ----------------------------------------------------------------------------------------------
+    for lvl in (10.0, 2.0, 0.0):
+        got = ow.filter_extreme_counts(pins["cnt_in"].copy(), level=lvl)
+        assert np.abs(got - pins[f"cnt_filter_{lvl}"]).max() < 1e-12
+    for s in (0, 1, 2, 5):
+        got = ow.box_sum_counts(pins["cnt_in"].copy(), s)
+        assert np.abs(got - pins[f"cnt_box_{s}"]).max() < 1e-12 * max(1.0, np.abs(pins[f"cnt_box_{s}"]).max())
+
+    # -- taper, power method -------------------------------------------------------------------------------------------
+    for key in [k for k in pins.files if k.startswith("taper_")]:
+        _, n0, n1, width = key.split("_")
+        assert np.abs(fftconv.taperf((int(n0), int(n1)), int(width)) - pins[key]).max() < 1e-15
+    a, b = pins["pm_a"], pins["pm_b"]
+    beta, vec, _ = fftconv.power_method(lambda z: a @ z @ b, pins["pm_b0"].shape, pins["pm_b0"].copy(), tol=1e-10, maxit=400)
+    assert abs(beta - float(pins["pm_beta"])) < 1e-12 * abs(beta)
+    assert np.abs(vec - pins["pm_vec"]).max() < 1e-12
+
+
+def test_product_host_code_vs_reference_run_fixtures(golden_dir):
+    """The product's HOST-side mirrors (no device work in them) against the same reference-run fixtures:
+    wgridder_conventions, taperf, the host loops of power_method and of the legacy primal_dual."""
+    from pfb_imaging_amd import opt
+    from pfb_imaging_amd.operators import gridder as pg
+    from pfb_imaging_amd.operators import hessian as ph
+
+    pins = np.load(f"{golden_dir}/ref_pins.npz")
+    for (l0, m0), want in zip(pins["conv_lm"], pins["conv_out"]):
+        assert [float(v) for v in pg.wgridder_conventions(l0, m0)] == list(want)
+    for key in [k for k in pins.files if k.startswith("taper_")]:
+        _, n0, n1, width = key.split("_")
+        assert np.abs(ph.taperf((int(n0), int(n1)), int(width)) - pins[key]).max() < 1e-15
+    a, b = pins["pm_a"], pins["pm_b"]
+    beta, vec = opt.power_method(lambda z: a @ z @ b, pins["pm_b0"].shape, b0=pins["pm_b0"].copy(), tol=1e-10, maxit=400,
+                                 verbosity=0)
+    assert abs(beta - float(pins["pm_beta"])) < 1e-12 * abs(beta)
+    assert np.abs(vec - pins["pm_vec"]).max() < 1e-12
+
+    from oracle import psi as opsi
+
+    q, h, rhs, w = pins["pd_q"], pins["pd_h"], pins["pd_b"], pins["pd_w"]
+    nband, nym, nxm = h.shape
+    for pos in (0, 1, 2):
+        x, v = opt.primal_dual(np.zeros((nband, nym, nxm)), np.zeros((nband, 2, nym, nxm)), float(pins["pd_lam"]),
+                               lambda c: c[:, 0] + np.einsum("ji,bjk->bik", q, c[:, 1]),
+                               lambda z: np.stack([z, np.einsum("ij,bjk->bik", q, z)], axis=1), float(h.max()),
+                               lambda c, s: opsi.prox_21m(c, s, weight=w), lambda z: h * z - rhs, nu=2.0, tol=1e-9,
+                               maxit=60, minit=10, positivity=pos, verbosity=0)
+        assert np.abs(x - pins[f"pd_x_{pos}"]).max() < 1e-12
+        assert np.abs(v - pins[f"pd_v_{pos}"]).max() < 1e-12
