@@ -266,7 +266,7 @@ def main():
     from pfb_imaging_amd.wgridder import Gridder
 
     _lib.require_gpu()  # fail loudly: no CPU path
-    # RCCL carries the band exchanges.  A communicator that fails to come up (all ranks agree on that over the gloo
+    # RCCL carries the band exchanges.  A communicator that fails to come up (all ranks agree on that over the TCP
     # rendezvous) costs the exchange, not the per-band measurement: it is then reported as skipped in config.parallelism.
     rccl_error = None
     try:
@@ -275,7 +275,7 @@ def main():
         if int(os.environ.get("WORLD_SIZE", "1")) == 1:
             raise
         rccl_error = f"{type(e).__name__}: {e}"
-        comm = BandComm.from_env(transport="gloo", set_device=False)
+        comm = BandComm.from_env(transport="host", set_device=False)
         _lib.check(_lib.lib().pfbhip_set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(_lib.device_count(), 1)))
     if comm.world_size > 1 and comm.min_over_ranks(0.0 if rccl_error else 1.0) == 0.0 and rccl_error is None:
         rccl_error = "RCCL communicator failed on another rank"
@@ -287,7 +287,7 @@ def main():
             raise SystemExit(3)
         print(f"[bench rank {comm.rank}] RCCL unavailable, band exchange skipped: {rccl_error}", file=sys.stderr, flush=True)
         if comm.transport == "rccl":  # ours came up but a peer's did not: stay off it
-            comm.transport = "gloo"
+            comm.transport = "host"
     rank, world = comm.rank, comm.world_size
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

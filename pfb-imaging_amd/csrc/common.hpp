@@ -114,7 +114,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Opt a kernel in to more than 64 KiB of dynamic LDS.  The attribute belongs to the (device, kernel) pair, so it is set
 // once per pair (thread-safe), not once per process: a process that builds handles on a second device (pfbhip_set_device,
-// one rank per GPU under torchrun) needs it there too.
+// one rank per GPU under a multi-process launcher) needs it there too.
 void allow_dynamic_lds(const void *kernel, int bytes);
 
 int64_t good_size_2357(int64_t n);

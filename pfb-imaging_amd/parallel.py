@@ -9,19 +9,177 @@ xGMI, as one large ``reduce(sum)`` to the root rank.
 
 Two transports sit behind the same methods:
   * ``rccl``  -- ``pfbhip_comm_*`` (RCCL over xGMI) on device buffers: the product path on GPUs;
-  * ``gloo``  -- ``torch.distributed`` on host tensors: only for CPU tests of the sharding /
-                 reduce logic (there is no GPU in the authoring container).
-``torch.distributed`` is also the launcher-side rendezvous (torchrun env) that carries RCCL's
-unique id from rank 0 to the other ranks; it is plumbing, not compute.
+  * ``host``  -- host arrays through :class:`HostGroup`, a plain TCP star on ``MASTER_ADDR``: the rendezvous that carries
+                 RCCL's 128-byte unique id from rank 0 to the other ranks, the scalar agreements between ranks
+                 (``min/max/sum_over_ranks``), and -- as a whole transport -- the CPU tests of the sharding / reduce logic
+                 (there is no GPU in the authoring container).  The launcher's environment (RANK / WORLD_SIZE /
+                 LOCAL_RANK / MASTER_ADDR / MASTER_PORT) is all that is read; no framework is imported.
 """
 
 import ctypes as ct
 import os
+import socket
+import struct
+import time
 
 import numpy as np
 
 from . import _lib
 from ._lib import DeviceArray, check, cint, i64, lib, ptr
+
+
+class HostGroup:
+    """Host-side process group over plain TCP: rank 0 listens, every other rank connects to it (a star).
+
+    The one primitive is ``allgather_bytes``; broadcast and the small reductions are built on it, summed in rank order on
+    every rank, so all ranks hold bit-identical results.  It moves rendezvous data and scalars in the product and whole
+    arrays only in CPU tests -- the images of the product path travel over RCCL.
+
+    Port: ``PFBHIP_RDZV_PORT`` if set, else the first of ``MASTER_PORT + 1 .. + 16`` rank 0 can bind (``MASTER_PORT`` itself
+    belongs to the launcher's own key-value store when the driver's launcher starts the ranks).  Each connection opens with a token that names the
+    job (``MASTER_PORT`` and world size), so a foreign listener on a candidate port is skipped, not talked to."""
+
+    MAGIC = b"PFBHIP1\0"
+    SPAN = 16
+
+    def __init__(self, rank, world, addr=None, port=None, timeout=None):
+        self.rank, self.world = int(rank), int(world)
+        self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        base = int(os.environ.get("MASTER_PORT", "29500")) if port is None else int(port)
+        fixed = os.environ.get("PFBHIP_RDZV_PORT") if port is None else str(port)
+        self.ports = [int(fixed)] if fixed else [base + 1 + k for k in range(self.SPAN)]
+        self.token = self.MAGIC + struct.pack("<qq", base, self.world)
+        self.timeout = float(os.environ.get("PFBHIP_RDZV_TIMEOUT", "300")) if timeout is None else float(timeout)
+        self.peers = []     # rank 0: sockets of ranks 1.., in rank order
+        self.sock = None    # other ranks: the socket to rank 0
+        if self.world > 1:
+            (self._listen if self.rank == 0 else self._connect)()
+
+    # -- wire helpers --------------------------------------------------------------------------------------------
+    @staticmethod
+    def _recv(sock, n):
+        buf = bytearray(n)
+        view, got = memoryview(buf), 0
+        while got < n:
+            k = sock.recv_into(view[got:], n - got)
+            if k == 0:
+                raise ConnectionError("HostGroup: peer closed the connection")
+            got += k
+        return bytes(buf)
+
+    @classmethod
+    def _send_msg(cls, sock, payload):
+        sock.sendall(struct.pack("<q", len(payload)) + payload)
+
+    @classmethod
+    def _recv_msg(cls, sock):
+        (n,) = struct.unpack("<q", cls._recv(sock, 8))
+        return cls._recv(sock, n)
+
+    def _listen(self):
+        srv, err = None, None
+        for p in self.ports:
+            try:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind(("" if self.addr not in ("127.0.0.1", "localhost") else "127.0.0.1", p))
+                break
+            except OSError as e:
+                srv.close()
+                srv, err = None, e
+        if srv is None:
+            raise RuntimeError(f"HostGroup: rank 0 cannot bind any of the ports {self.ports}: {err}")
+        srv.listen(self.world + 8)
+        srv.settimeout(1.0)
+        deadline = time.time() + self.timeout
+        got = {}
+        while len(got) < self.world - 1:
+            if time.time() > deadline:
+                srv.close()
+                raise TimeoutError(f"HostGroup: {len(got) + 1} of {self.world} ranks arrived within {self.timeout:.0f} s")
+            try:
+                c, _ = srv.accept()
+            except socket.timeout:
+                continue
+            try:
+                c.settimeout(5.0)
+                hello = self._recv(c, len(self.token) + 8)
+                (r,) = struct.unpack("<q", hello[len(self.token):])
+                if hello[:len(self.token)] != self.token or not 0 < r < self.world or r in got:
+                    raise ConnectionError("not ours")
+                c.sendall(self.MAGIC)
+                c.settimeout(None)
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                got[r] = c
+            except (OSError, struct.error):
+                c.close()
+        srv.close()
+        self.peers = [got[r] for r in range(1, self.world)]
+
+    def _connect(self):
+        deadline = time.time() + self.timeout
+        hello = self.token + struct.pack("<q", self.rank)
+        while True:
+            for p in self.ports:
+                try:
+                    s = socket.create_connection((self.addr, p), timeout=3.0)
+                except OSError:
+                    continue
+                try:
+                    s.settimeout(4.0)
+                    s.sendall(hello)
+                    if self._recv(s, len(self.MAGIC)) == self.MAGIC:
+                        s.settimeout(None)
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self.sock = s
+                        return
+                except OSError:
+                    pass
+                s.close()
+            if time.time() > deadline:
+                raise TimeoutError(f"HostGroup: rank {self.rank} found no rank 0 on {self.addr}:{self.ports} within "
+                                   f"{self.timeout:.0f} s")
+            time.sleep(0.05)
+
+    # -- collectives ---------------------------------------------------------------------------------------------
+    def allgather_bytes(self, payload):
+        """Every rank's payload, as a list in rank order, on every rank."""
+        payload = bytes(payload)
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [self._recv_msg(c) for c in self.peers]
+            blob = b"".join(struct.pack("<q", len(p)) + p for p in parts)
+            for c in self.peers:
+                self._send_msg(c, blob)
+            return parts
+        self._send_msg(self.sock, payload)
+        blob, parts, off = self._recv_msg(self.sock), [], 0
+        for _ in range(self.world):
+            (n,) = struct.unpack_from("<q", blob, off)
+            parts.append(blob[off + 8:off + 8 + n])
+            off += 8 + n
+        return parts
+
+    def bcast_bytes(self, payload, src=0):
+        return self.allgather_bytes(payload if self.rank == src else b"")[src]
+
+    def allgather(self, arr):
+        """float64 blocks of equal shape from every rank, stacked along a new leading axis (rank order)."""
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        parts = self.allgather_bytes(arr.tobytes())
+        return np.stack([np.frombuffer(p, dtype=np.float64).reshape(arr.shape) for p in parts])
+
+    def barrier(self):
+        self.allgather_bytes(b"")
+
+    def close(self):
+        for c in self.peers + ([self.sock] if self.sock is not None else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers, self.sock = [], None
 
 
 def band_owner(band, world_size):
@@ -32,42 +190,47 @@ def local_bands(nband, rank, world_size):
     return [b for b in range(nband) if band_owner(b, world_size) == rank]
 
 
+_HOST_GROUPS = {}
+
+
 class BandComm:
-    def __init__(self, rank=0, world_size=1, local_rank=0, transport=None):
+    def __init__(self, rank=0, world_size=1, local_rank=0, transport=None, host=None):
         self.rank, self.world_size, self.local_rank = rank, world_size, local_rank
         self.transport = transport
         self._h = None
-        self._dist = None
+        self._host = host   # HostGroup (or a test stand-in with the same methods) when world_size > 1
 
     # -- construction ------------------------------------------------------
     @classmethod
-    def from_env(cls, transport=None, set_device=True):
-        """Build from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
+    def from_env(cls, transport=None, set_device=True, host=None):
+        """Build from the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).
+
+        ``transport``: "rccl" (default on a box with GPUs) or "host" (host arrays over :class:`HostGroup`; CPU tests).
+        ``host`` replaces the TCP group by an object with the same methods (the gloo stand-in of the CPU tests)."""
         rank = int(os.environ.get("RANK", "0"))
         world = int(os.environ.get("WORLD_SIZE", "1"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if transport is None:
-            transport = "rccl" if _lib.device_count() > 0 else "gloo"
-        self = cls(rank, world, local_rank, transport)
+            transport = "rccl" if _lib.device_count() > 0 else "host"
+        if transport not in ("rccl", "host"):
+            raise ValueError(f"unknown transport {transport!r} (rccl | host)")
+        self = cls(rank, world, local_rank, transport, host)
         if transport == "rccl" and set_device:
             ndev = _lib.device_count()
             check(lib().pfbhip_set_device(cint(local_rank % max(ndev, 1))))
-        if world > 1:
-            import torch.distributed as dist
-
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if not dist.is_initialized():
-                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            self._dist = dist
+        if world > 1 and self._host is None:
+            # one TCP group per process and job: a second communicator (bench.py's fallback when RCCL fails on SOME rank)
+            # must not make the ranks rendezvous again -- the ranks that did not fail would not come
+            key = (rank, world, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))
+            if key not in _HOST_GROUPS:
+                _HOST_GROUPS[key] = HostGroup(rank, world)
+            self._host = _HOST_GROUPS[key]
         if transport == "rccl":
             uid = np.zeros(_lib.UNIQUE_ID_BYTES, dtype=np.uint8)
             if rank == 0:
                 check(lib().pfbhip_comm_unique_id(ptr(uid)))
-            if world > 1:
-                import torch
-
-                t = torch.from_numpy(uid)
-                self._dist.broadcast(t, src=0)
+            if world > 1:  # RCCL's unique id travels rank 0 -> all over the TCP group
+                uid = np.frombuffer(self._host.bcast_bytes(uid.tobytes(), src=0), dtype=np.uint8).copy()
             h = ct.c_void_p()
             check(lib().pfbhip_comm_create(ptr(uid), cint(world), cint(rank), ct.byref(h)))
             self._h = h
@@ -77,6 +240,7 @@ class BandComm:
         if self._h is not None and self._h.value:
             lib().pfbhip_comm_destroy(self._h)
             self._h = None
+        self._host = None   # the process-wide TCP group stays up for later communicators (closed at exit)
 
     # -- collectives ----------------------------------------------------------
     def barrier(self):
@@ -85,7 +249,7 @@ class BandComm:
         if self.transport == "rccl":
             check(lib().pfbhip_comm_barrier(self._h))
         else:
-            self._dist.barrier()
+            self._host.barrier()
 
     def reduce_sum_dev(self, send, recv, root=0):
         """RCCL sum-to-root of device buffers (the product's band reduce)."""
@@ -109,11 +273,8 @@ class BandComm:
             out = _lib.result_empty(arr.shape, np.float64) if self.rank == root else None
             check(lib().pfbhip_comm_reduce_sum_host(self._h, ptr(arr), ptr(out), i64(arr.size), cint(root)))
             return out
-        import torch
-
-        t = torch.from_numpy(arr.copy())
-        self._dist.reduce(t, dst=root)
-        return t.numpy() if self.rank == root else None
+        tot = self._host.allgather(arr).sum(axis=0)
+        return tot if self.rank == root else None
 
     def allreduce_sum(self, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
@@ -123,11 +284,7 @@ class BandComm:
             out = arr.copy()
             check(lib().pfbhip_comm_allreduce_sum_host(self._h, ptr(out), i64(out.size)))
             return out
-        import torch
-
-        t = torch.from_numpy(arr.copy())
-        self._dist.all_reduce(t)
-        return t.numpy()
+        return self._host.allgather(arr).sum(axis=0)
 
     def allgather(self, arr):
         """Blocks of equal shape from every rank, stacked along a new leading axis (rank order)."""
@@ -138,38 +295,19 @@ class BandComm:
             out = _lib.result_empty((self.world_size,) + arr.shape, np.float64)
             check(lib().pfbhip_comm_allgather_host(self._h, ptr(arr), ptr(out), i64(arr.size)))
             return out
-        import torch
+        return self._host.allgather(arr)
 
-        parts = [torch.empty(arr.shape, dtype=torch.float64) for _ in range(self.world_size)]
-        self._dist.all_gather(parts, torch.from_numpy(arr.copy()))
-        return np.stack([p.numpy() for p in parts])
+    def _scalars(self, value):
+        return self._host.allgather(np.array([float(value)]))[:, 0]
 
     def max_over_ranks(self, value):
-        if self.world_size == 1:
-            return float(value)
-        import torch
-
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return float(t[0])
+        return float(value) if self.world_size == 1 else float(self._scalars(value).max())
 
     def min_over_ranks(self, value):
-        if self.world_size == 1:
-            return float(value)
-        import torch
-
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN)
-        return float(t[0])
+        return float(value) if self.world_size == 1 else float(self._scalars(value).min())
 
     def sum_over_ranks(self, value):
-        if self.world_size == 1:
-            return float(value)
-        import torch
-
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self._dist.all_reduce(t)
-        return float(t[0])
+        return float(value) if self.world_size == 1 else float(self._scalars(value).sum())
 
 
 def row_block(nrow, rank, world_size):

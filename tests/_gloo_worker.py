@@ -1,4 +1,7 @@
-"""Worker for tests/test_parallel_cpu.py: run under torch.distributed.run with 2 ranks (gloo, CPU)."""
+"""Worker for tests/test_parallel_cpu.py, 2 ranks on the CPU, two ways:
+  * ``_gloo_worker.py socket``: plain processes, the product's own TCP rendezvous / host transport (parallel.HostGroup);
+  * ``_gloo_worker.py gloo`` under torch.distributed.run: torch.distributed (gloo) stands in for the host transport through
+    :class:`GlooHost` -- test-only, the product itself imports no torch."""
 
 import os
 import sys
@@ -53,8 +56,57 @@ class FakeWorker:
         return out[0]
 
 
+class GlooHost:
+    """HostGroup's methods over torch.distributed (gloo): ``allgather_bytes`` is the one primitive there too."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            dist.init_process_group(backend="gloo")
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allgather_bytes(self, payload):
+        torch, dist = self.torch, self.dist
+        n = torch.tensor([len(payload)], dtype=torch.int64)
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        dist.all_gather(sizes, n)
+        m = max(int(s[0]) for s in sizes)
+        buf = torch.zeros(max(m, 1), dtype=torch.uint8)
+        if payload:
+            buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        parts = [torch.zeros(max(m, 1), dtype=torch.uint8) for _ in range(self.world)]
+        dist.all_gather(parts, buf)
+        return [bytes(p[:int(s[0])].numpy().tobytes()) for p, s in zip(parts, sizes)]
+
+    def bcast_bytes(self, payload, src=0):
+        return self.allgather_bytes(payload if self.rank == src else b"")[src]
+
+    def allgather(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        return np.stack([np.frombuffer(p, dtype=np.float64).reshape(arr.shape) for p in self.allgather_bytes(arr.tobytes())])
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        pass
+
+
 def main():
-    comm = BandComm.from_env(transport="gloo")
+    mode = sys.argv[1] if len(sys.argv) > 1 else "socket"
+    comm = BandComm.from_env(transport="host", host=GlooHost() if mode == "gloo" else None)
+    if mode == "socket":
+        from pfb_imaging_amd.parallel import HostGroup
+
+        assert isinstance(comm._host, HostGroup) and "torch" not in sys.modules
+        # the rendezvous payload of the product path: 128 bytes from rank 0 (RCCL's unique id travels like this)
+        uid = bytes(range(128)) if comm.rank == 0 else b""
+        assert comm._host.bcast_bytes(uid, src=0) == bytes(range(128))
+        assert comm._host.allgather_bytes(bytes([comm.rank]) * (comm.rank + 1)) == [b"\x00", b"\x01\x01"]
     assert comm.world_size == 2
     nband, nx, ny = 5, 6, 4
     rng = np.random.default_rng(0)  # same data on every rank
@@ -143,7 +195,7 @@ def main():
     tree1 = HessTreeRay([diag[0]], nx, ny, 2 * nx, 2 * ny, etas=0.5, workers=pool1)
     np.testing.assert_allclose(tree1.dot(x[:1]), ((diag[0] + 0.5) * x[0])[None], rtol=1e-14)
     np.testing.assert_allclose(tree1.cg(((diag[0] + 0.5) * x[0])[None]), x[:1], rtol=1e-13)
-    assert PrimalDual._hess_bands(tree1, 1) is None  # gloo transport: every rank agrees on the generic loop
+    assert PrimalDual._hess_bands(tree1, 1) is None  # host transport: every rank agrees on the generic loop
     psi1 = PsiNocopytRay(1, px, py, ("self", "db1"), 2, workers=pool1)
     full1 = opsi.Psi(1, px, py, ("self", "db1"), 2)
     assert (psi1.nxmax, psi1.nymax) == (full1.nxmax, full1.nymax)  # the bandless rank learned the shape from the others

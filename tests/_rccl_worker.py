@@ -47,6 +47,29 @@ def main():
     assert np.array_equal(comm.allgather(img[rank]), img)
     assert comm.max_over_ranks(rank) == world - 1 and comm.sum_over_ranks(1.0) == world
 
+    # --- per-collective timings (printed by rank 0: the first N > 1 run on hardware yields numbers without a code change) ---
+    import time
+
+    for n in (1 << 20, 8192 * 8192 // 8, 8192 * 8192):       # 8 MB, 67 MB, 537 MB (one C2 image) of f64
+        a, b = DeviceArray((n,), np.float64), DeviceArray((n,), np.float64)
+        a.upload(np.ones(n))
+        for name, call in (("reduce", lambda: comm.reduce_sum_dev(a, b if rank == 0 else None, root=0)),
+                           ("allreduce", lambda: comm.allreduce_sum_dev(a, b))):
+            call()
+            comm.barrier()
+            _lib.check(_lib.lib().pfbhip_synchronize())
+            t0 = time.perf_counter()
+            for _ in range(3):
+                call()
+            _lib.check(_lib.lib().pfbhip_synchronize())
+            comm.barrier()
+            dt = (time.perf_counter() - t0) / 3
+            if rank == 0:
+                print(f"[rccl timing] world {world} {name:9s} {8 * n / 1e6:8.1f} MB  {dt * 1e3:8.3f} ms  "
+                      f"{8 * n / dt / 1e9:7.1f} GB/s (algorithmic)", flush=True)
+        a.free()
+        b.free()
+
     # --- band pool: PSF Hessians per band, one band (or two) per GPU ---
     nband = 2 * world
     nx, ny, nxp, nyp = 64, 48, 128, 96
