@@ -16,6 +16,8 @@ SARA dictionary of ``operators.psi`` on the band's GPU; ``dual_update`` is the b
 ``dual_update_numba_fast`` (prox/prox_21m.py:105-135): the band sum is completed with ONE all-reduce.
 """
 
+import os
+
 import numpy as np
 
 from .. import _lib
@@ -45,8 +47,10 @@ class _BandWorkerImpl:
             self._resid = None
 
     def load_band(self, store_url, node_name):
-        """Read this band's inputs from the ``.dt`` store (band_worker.py:61-106): ``store_url`` is a store path (opened
-        with xarray, as the reference does) or an already-open store / in-memory mapping (see ``pfb_imaging_amd.store``).
+        """Read this band's inputs from the ``.dt`` store (band_worker.py:61-106): ``store_url`` is a store path -- a local
+        zarr-v2 directory store is read by this package's own reader (``store.DirStore``: chunk files straight into pinned
+        memory, no xarray / zarr needed), anything else is opened with xarray, as the reference does -- or an already-open
+        store / in-memory mapping (see ``pfb_imaging_amd.store``).
         Every array is decoded straight into page-locked memory and stays with this worker; the device plans built from
         them upload at the PCIe rate."""
         import gc
@@ -55,7 +59,14 @@ class _BandWorkerImpl:
 
         try:
             store = store_url
-            if isinstance(store_url, (str, bytes)):
+            if isinstance(store_url, bytes):
+                store_url = store_url.decode()
+            local = store_url[len("file://"):] if isinstance(store_url, str) and store_url.startswith("file://") else store_url
+            if isinstance(local, (str, os.PathLike)) and os.path.exists(os.path.join(os.fspath(local), ".zgroup")):
+                from ..store import open_store
+
+                store = open_store(local)
+            elif isinstance(store_url, str):
                 try:
                     import xarray as xr
                 except ImportError as e:  # pragma: no cover - the storage stack is not part of this package
