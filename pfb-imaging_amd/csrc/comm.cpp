@@ -27,8 +27,10 @@ struct pfbhip_comm {
     int nranks = 1, rank = 0;
     // persistent device staging of the host-array collectives (grow-only: no hipMalloc per call)
     pfbhip::DevBuf<double> stage_a, stage_b;
+    double *barrier_word = nullptr;
     ~pfbhip_comm()
     {
+        if (barrier_word) pfbhip::dev_free(barrier_word, sizeof(double));
         if (comm) ncclCommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -62,6 +64,10 @@ int pfbhip_comm_create(const uint8_t *id, int nranks, int rank, pfbhip_comm **ou
         ncclUniqueId uid;
         std::memcpy(&uid, id, sizeof uid);
         PFB_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // RCCL allocates its buffers with hipMalloc behind our back and never sees the handles' cache of released blocks;
+        // communicator creation is a collective (one rank cannot retry alone) and happens once per run, so the cache is
+        // simply given back first
+        (void)dev_cache_bytes(true);
         PFB_NCCL(ncclCommInitRank(&c->comm, nranks, uid, rank));
         *out = c.release();
     });
@@ -155,14 +161,11 @@ int pfbhip_comm_barrier(pfbhip_comm *c)
     return guarded([&] {
         PFB_REQUIRE(c, "NULL argument");
         // a 1-element all-reduce on a scratch word is RCCL's barrier
-        double *w = nullptr;
-        PFB_HIP(hipMalloc(reinterpret_cast<void **>(&w), sizeof(double)));
+        if (c->barrier_word == nullptr) c->barrier_word = static_cast<double *>(dev_alloc(sizeof(double)));
+        double *w = c->barrier_word;
         PFB_HIP(hipMemsetAsync(w, 0, sizeof(double), c->stream));
-        ncclResult_t r = ncclAllReduce(w, w, 1, ncclDouble, ncclSum, c->comm, c->stream);
-        hipError_t e = hipStreamSynchronize(c->stream);
-        (void)hipFree(w);
-        PFB_NCCL(r);
-        PFB_HIP(e);
+        PFB_NCCL(ncclAllReduce(w, w, 1, ncclDouble, ncclSum, c->comm, c->stream));
+        PFB_HIP(hipStreamSynchronize(c->stream));
     });
 }
 

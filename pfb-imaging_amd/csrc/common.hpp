@@ -68,12 +68,27 @@ int guarded(F &&body) noexcept
 // ~45 ms per GB on this platform (27 GB: 0.7-1.3 s; tools/malloc_probe.cpp) and a C5-size plan holds ~100 GB, so the second
 // plan of a geometry -- the next band, the next major cycle -- used to spend 5 s allocating what the first one had just
 // freed.  Blocks of >= 32 MiB are kept on release (exact-size reuse, per device, bounded by PFBHIP_DEVCACHE_MB, default
-// 131072; 0 disables) and everything cached is given back when an allocation fails.  Like hipFree, releasing a block waits for
+// 40 % of the device's memory; 0 disables) and everything cached is given back when an allocation fails -- one of ours
+// (dev_alloc, pfbhip_malloc) or one made inside a library on our behalf (rocFFT plan creation, RCCL communicator
+// creation: retry_after_cache_flush below).  pfbhip_mem_info counts cached blocks as free.  Like hipFree, releasing a block waits for
 // the device first.  PFBHIP_DEVCACHE_POISON=1 fills every block handed out with 0xFF bytes (NaNs): no kernel may rely on
 // fresh memory being zero.
 void *dev_alloc(size_t bytes);
 void dev_free(void *p, size_t bytes) noexcept;
 size_t dev_cache_bytes(bool flush) noexcept;
+bool dev_cache_release_for_retry() noexcept;  // flushes; true when something was given back
+
+// Calls that allocate device memory inside a library (rocfft_plan_create, ncclCommInitRank ...) never see the cache, so
+// an allocation failure there may be ours to cure: run `call` (returns true on success); on failure give the cached
+// blocks back and run it once more.
+template <class F>
+bool retry_after_cache_flush(F &&call)
+{
+    if (call()) return true;
+    (void)hipGetLastError();
+    if (!dev_cache_release_for_retry()) return false;
+    return call();
+}
 
 // Owning device buffer.
 template <class T>

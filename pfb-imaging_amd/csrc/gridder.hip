@@ -1880,9 +1880,15 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         any_rocfft = true;
         rocfft_plan pl = nullptr;
         size_t lengths[1] = {size_t(len)};
-        PFB_ROCFFT(rocfft_plan_create(&pl, rocfft_placement_inplace,
-                                      forward ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
-                                      rocfft_precision_double, 1, lengths, size_t(batch), nullptr));
+        rocfft_status st = rocfft_status_success;
+        // (rocFFT allocates inside plan creation: on failure the cache of released blocks gives way, once)
+        if (!retry_after_cache_flush([&] {
+                st = rocfft_plan_create(&pl, rocfft_placement_inplace,
+                                        forward ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
+                                        rocfft_precision_double, 1, lengths, size_t(batch), nullptr);
+                return st == rocfft_status_success;
+            }))
+            PFB_ROCFFT(st);
         size_t w = 0;
         PFB_ROCFFT(rocfft_plan_get_work_buffer_size(pl, &w));
         wmax = std::max(wmax, w);

@@ -85,7 +85,8 @@ bool RowFFT::init(int64_t N)
             long double a = -2.0L * pi * (long double)k / (long double)N;
             tw[size_t(n1 + k)] = make_double2(double(cosl(a)), double(sinl(a)));
         }
-    PFB_HIP(hipMalloc(reinterpret_cast<void **>(&d_tw), tw.size() * sizeof(double2)));
+    d_tw = static_cast<double2 *>(dev_alloc(tw.size() * sizeof(double2)));
+    d_tw_bytes = tw.size() * sizeof(double2);
     PFB_HIP(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice));
     pl.twiddle = d_tw;
     ok = true;
@@ -94,8 +95,9 @@ bool RowFFT::init(int64_t N)
 
 void RowFFT::release()
 {
-    if (d_tw) (void)hipFree(d_tw);
+    if (d_tw) dev_free(d_tw, d_tw_bytes);
     d_tw = nullptr;
+    d_tw_bytes = 0;
     ok = false;
 }
 

@@ -10,6 +10,7 @@ namespace pfbhip {
 struct RowFFT {
     RowFFTPlan pl;
     double2 *d_tw = nullptr;
+    size_t d_tw_bytes = 0;
     bool ok = false;
     bool init(int64_t N);  // false if N is not supported
     void release();

@@ -76,13 +76,29 @@ struct DevCache {
     std::mutex mu;
     std::multimap<std::pair<int, size_t>, void *> blocks;  // (device, bytes) -> block
     size_t cached = 0;
-    size_t limit = size_t(131072) << 20;
+    size_t limit = ~size_t(0);   // "not set yet": 40 % of the device's memory at the first release (see bound())
+    bool limit_from_env = false;
     bool poison = false;
     static constexpr size_t MIN_BLOCK = size_t(32) << 20;
     DevCache()
     {
-        if (const char *e = std::getenv("PFBHIP_DEVCACHE_MB")) limit = size_t(std::max(0ll, std::atoll(e))) << 20;
+        if (const char *e = std::getenv("PFBHIP_DEVCACHE_MB")) {
+            limit = size_t(std::max(0ll, std::atoll(e))) << 20;
+            limit_from_env = true;
+        }
         if (const char *e = std::getenv("PFBHIP_DEVCACHE_POISON")) poison = e[0] == '1';
+    }
+    // Default bound: 40 % of the device's memory (115 GB of 288) -- one C5-size plan's blocks survive a plan change, and
+    // allocators that never see this cache (rocFFT's plan internals, RCCL's buffers, other libraries in the process)
+    // keep the larger share whatever has been released.  Called with mu held.
+    size_t bound()
+    {
+        if (limit == ~size_t(0)) {
+            size_t f = 0, t = 0;
+            limit = hipMemGetInfo(&f, &t) == hipSuccess ? t / 10 * 4 : size_t(65536) << 20;
+            (void)hipGetLastError();
+        }
+        return limit;
     }
     // (never destroyed: blocks still cached at process exit go with the context)
 };
@@ -117,7 +133,7 @@ void *dev_alloc(size_t bytes)
     void *p = nullptr;
     int dev = 0;
     PFB_HIP(hipGetDevice(&dev));
-    if (bytes >= DevCache::MIN_BLOCK && c.limit > 0) {
+    if (bytes >= DevCache::MIN_BLOCK) {
         std::lock_guard<std::mutex> lk(c.mu);
         auto it = c.blocks.find(std::make_pair(dev, bytes));
         if (it != c.blocks.end()) {
@@ -136,10 +152,19 @@ void *dev_alloc(size_t bytes)
         PFB_HIP(err);
     }
     if (c.poison) {
-        PFB_HIP(hipMemset(p, 0xFF, bytes));
-        PFB_HIP(hipDeviceSynchronize());
+        hipError_t e = hipMemset(p, 0xFF, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            (void)hipFree(p);  // the block is neither handed out nor cached: give it back
+            PFB_HIP(e);
+        }
     }
     return p;
+}
+
+bool dev_cache_release_for_retry() noexcept
+{
+    return dev_cache_bytes(true) > 0;
 }
 
 void dev_free(void *p, size_t bytes) noexcept
@@ -152,7 +177,7 @@ void dev_free(void *p, size_t bytes) noexcept
         // a block goes back to the cache of the device it lives on; like hipFree, not before the device is done with it
         if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.device == dev && hipDeviceSynchronize() == hipSuccess) {
             std::lock_guard<std::mutex> lk(c.mu);
-            if (c.cached + bytes <= c.limit) {
+            if (c.cached + bytes <= c.bound()) {
                 c.blocks.emplace(std::make_pair(dev, bytes), p);
                 c.cached += bytes;
                 return;
@@ -225,6 +250,7 @@ int pfbhip_mem_info(size_t *free_bytes, size_t *total_bytes)
     return guarded([&] {
         size_t f = 0, t = 0;
         PFB_HIP(hipMemGetInfo(&f, &t));
+        f += pfbhip::dev_cache_bytes(false);  // released blocks waiting for reuse are available memory, not use
         if (free_bytes) *free_bytes = f;
         if (total_bytes) *total_bytes = t;
     });
