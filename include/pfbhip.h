@@ -94,7 +94,7 @@ typedef struct pfbhip_gridder_params {
     int32_t verbosity;
     /* 0 / 0.0 = automatic.  Tests pin the kernel row / w-plane scheme with these. */
     int32_t force_W;
-    int32_t force_wmode; /* 0 auto, 1 ES-kernel w-planes, 2 polynomial (Chebyshev-node) w-planes */
+    int32_t force_wmode; /* 0 auto, 1 ES-kernel w-planes, 2 polynomial (Chebyshev-node) w-planes, 3 one plane (differentiated kernels) */
     double force_sigma;
 } pfbhip_gridder_params;
 
@@ -112,7 +112,7 @@ typedef struct pfbhip_gridder_info {
      * w-stacking; each visibility touches W planes).  wmode 1: the w range [wcenter - whalf,
      * wcenter + whalf] is interpolated by a degree-(nplanes-1) polynomial through Chebyshev
      * nodes (each visibility touches all planes with Lagrange weights; no w-correction in the
-     * image).  The cheaper admissible scheme is chosen per plan. */
+     * image).  wmode 2: see nderiv below.  The cheapest admissible scheme is chosen per plan. */
     int32_t wmode;
     int32_t occ_rows;      /* rows of the uv-plane that hold visibilities (only these are cleared / transformed) */
     double wcenter, whalf;
@@ -137,6 +137,12 @@ typedef struct pfbhip_gridder_info {
      * phase (small w x field), separable form (per-plane column table x row factor x residual polynomials), and the rest
      * (n - 1 polynomial + sincos per pixel and plane) */
     int32_t screen_composite, screen_separable;
+    /* wmode 2 (round 4): ONE uv-plane at wcenter; the rest of the w-term, exp(-2 pi i (w - wcenter)(n - 1 + nshift)), is
+     * interpolated in s = l^2 + m^2 through nderiv Chebyshev nodes of [0, smax] and carried by the gridding kernel of each
+     * visibility: multiplication by s^k in the image = the 2k-th derivatives of the kernel on the uv-plane (nderiv kernel
+     * functions per axis; phase centre on axis only).  Replaces the nderiv planes wmode 1 would use. */
+    int32_t nderiv;
+    double smax;
 } pfbhip_gridder_info;
 
 int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw_host /* (nrow,3) */,

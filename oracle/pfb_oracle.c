@@ -440,3 +440,159 @@ void pfbo_set_num_threads(int n)
     (void)n;
 #endif
 }
+
+/* -------------------------------------------------------------------------------------------------------
+ * wmode 2: ONE uv-plane, the w-term of every visibility folded into its gridding kernel.
+ *
+ *   exp(-2 pi i w t(s)) = exp(-2 pi i wc t) * E(dw; s),  s = l^2 + m^2 (phase centre on axis),  dw = w - wc,
+ *   E(dw; s) ~ sum_k C_k(dw) (s / smax)^k                (Chebyshev interpolation in s at K nodes)
+ *   multiplication by l^2 in the image  <->  -(nu px / (pi W))^2 d^2/dx^2 of the u-kernel phi(x)
+ *
+ * so a visibility's footprint is  sum_k C_k D^k[phi(x) phi(y)],  D^k = sum_r binom(k, r) a_r(x) b_{k-r}(y), with
+ * a_r / b_r the 2r-th derivatives of the kernel polynomial scaled by (-alpha_u / smax)^r / (-alpha_v / smax)^r
+ * (tables dtab_u / dtab_v, (K, W, D + 1), built by oracle/wgridder.py).  cw (n, K) complex are the C_k of every
+ * visibility (the gridding direction; the gather conjugates them).
+ * ------------------------------------------------------------------------------------------------------- */
+static inline void wd_taps(int K, int W, int D, const double *dtab, int i0, double p, double *out /* (K, 32) */)
+{
+    double z = 2.0 * ((p + (1.0 - 0.5 * (double)W)) - (double)i0) - 1.0;
+    for (int k = 0; k < K; ++k)
+        for (int a = 0; a < W; ++a) {
+            const double *c = dtab + ((size_t)k * (size_t)W + (size_t)a) * (size_t)(D + 1);
+            double v = c[D];
+            for (int q = D - 1; q >= 0; --q) v = fma(v, z, c[q]);
+            out[k * 32 + a] = v;
+        }
+}
+
+static const double wd_binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
+
+void pfbo_grid_plane_wd(int64_t ntiles, const int64_t *tstart, const int64_t *order, const double *pu, const double *pv,
+                        const int32_t *iu0, const int32_t *iv0, const double *cw /* (n, K, 2) */,
+                        const double *sval /* (n, 2) */, int K, int W, const double *dtab_u, const double *dtab_v, int D,
+                        int64_t nu, int64_t nv, int T, double *grid /* (nu, nv, 2) zeroed */)
+{
+    const int L = T + W - 1;
+    const int64_t ntv = (nv + T - 1) / T;
+#pragma omp parallel
+    {
+        double *loc = (double *)malloc(sizeof(double) * (size_t)L * L * 2);
+        double ak[4 * 32], bk[4 * 32], sr[4][32], si[4][32];
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t t = 0; t < ntiles; ++t) {
+            if (tstart[t + 1] == tstart[t]) continue;
+            int64_t bu = (t / ntv) * T, bv = (t % ntv) * T;
+            memset(loc, 0, sizeof(double) * (size_t)L * L * 2);
+            for (int64_t q = tstart[t]; q < tstart[t + 1]; ++q) {
+                int64_t i = order[q];
+                int64_t lu = wrapi(iu0[i], nu) - bu, lv = wrapi(iv0[i], nv) - bv;
+                wd_taps(K, W, D, dtab_u, iu0[i], pu[i], ak);
+                wd_taps(K, W, D, dtab_v, iv0[i], pv[i], bk);
+                /* P_k = val * C_k;  S_r(col) = sum_m binom(r + m, r) P_{r+m} b_m(col) */
+                double pr[4], pi[4];
+                for (int k = 0; k < K; ++k) {
+                    double cr = cw[((size_t)i * K + k) * 2], ci = cw[((size_t)i * K + k) * 2 + 1];
+                    pr[k] = sval[2 * i] * cr - sval[2 * i + 1] * ci;
+                    pi[k] = sval[2 * i] * ci + sval[2 * i + 1] * cr;
+                }
+                for (int r = 0; r < K; ++r)
+                    for (int b = 0; b < W; ++b) {
+                        double xr = 0.0, xi = 0.0;
+                        for (int m = 0; r + m < K; ++m) {
+                            xr += wd_binom[r + m][r] * pr[r + m] * bk[m * 32 + b];
+                            xi += wd_binom[r + m][r] * pi[r + m] * bk[m * 32 + b];
+                        }
+                        sr[r][b] = xr;
+                        si[r][b] = xi;
+                    }
+                for (int a = 0; a < W; ++a) {
+                    double *row = loc + ((size_t)(lu + a) * L + (size_t)lv) * 2;
+                    for (int b = 0; b < W; ++b) {
+                        double xr = 0.0, xi = 0.0;
+                        for (int r = 0; r < K; ++r) {
+                            xr += ak[r * 32 + a] * sr[r][b];
+                            xi += ak[r * 32 + a] * si[r][b];
+                        }
+                        row[2 * b] += xr;
+                        row[2 * b + 1] += xi;
+                    }
+                }
+            }
+            for (int a = 0; a < L; ++a) {
+                int64_t gu = wrapi(bu + a, nu);
+                for (int b = 0; b < L; ++b) {
+                    double re = loc[((size_t)a * L + b) * 2], im = loc[((size_t)a * L + b) * 2 + 1];
+                    if (re == 0.0 && im == 0.0) continue;
+                    int64_t gv = wrapi(bv + b, nv);
+                    double *g = grid + ((size_t)gu * (size_t)nv + (size_t)gv) * 2;
+#pragma omp atomic
+                    g[0] += re;
+#pragma omp atomic
+                    g[1] += im;
+                }
+            }
+        }
+        free(loc);
+    }
+}
+
+/* Gather: acc (n, 2) += sum_cells grid(cell) * conj(kernel of the visibility)(cell)  (the kernel's a_r, b_r are real:
+ * only the C_k are conjugated). */
+void pfbo_degrid_plane_wd(int64_t ntiles, const int64_t *tstart, const int64_t *order, const double *pu, const double *pv,
+                          const int32_t *iu0, const int32_t *iv0, const double *cw, int K, int W, const double *dtab_u,
+                          const double *dtab_v, int D, int64_t nu, int64_t nv, int T, const double *grid, double *acc)
+{
+    const int L = T + W - 1;
+    const int64_t ntv = (nv + T - 1) / T;
+#pragma omp parallel
+    {
+        double *loc = (double *)malloc(sizeof(double) * (size_t)L * L * 2);
+        double ak[4 * 32], bk[4 * 32];
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t t = 0; t < ntiles; ++t) {
+            if (tstart[t + 1] == tstart[t]) continue;
+            int64_t bu = (t / ntv) * T, bv = (t % ntv) * T;
+            for (int a = 0; a < L; ++a) {
+                int64_t gu = wrapi(bu + a, nu);
+                for (int b = 0; b < L; ++b) {
+                    int64_t gv = wrapi(bv + b, nv);
+                    const double *g = grid + ((size_t)gu * (size_t)nv + (size_t)gv) * 2;
+                    loc[((size_t)a * L + b) * 2] = g[0];
+                    loc[((size_t)a * L + b) * 2 + 1] = g[1];
+                }
+            }
+            for (int64_t q = tstart[t]; q < tstart[t + 1]; ++q) {
+                int64_t i = order[q];
+                int64_t lu = wrapi(iu0[i], nu) - bu, lv = wrapi(iv0[i], nv) - bv;
+                wd_taps(K, W, D, dtab_u, iu0[i], pu[i], ak);
+                wd_taps(K, W, D, dtab_v, iv0[i], pv[i], bk);
+                /* T_r(col) = sum_rows a_r(row) grid(row, col);  D_k = sum_col sum_{r <= k} binom(k, r) b_{k-r}(col) T_r(col) */
+                double dr[4] = {0, 0, 0, 0}, di[4] = {0, 0, 0, 0};
+                for (int b = 0; b < W; ++b) {
+                    double tr[4] = {0, 0, 0, 0}, ti[4] = {0, 0, 0, 0};
+                    for (int a = 0; a < W; ++a) {
+                        const double *cell = loc + ((size_t)(lu + a) * L + (size_t)(lv + b)) * 2;
+                        for (int r = 0; r < K; ++r) {
+                            tr[r] += ak[r * 32 + a] * cell[0];
+                            ti[r] += ak[r * 32 + a] * cell[1];
+                        }
+                    }
+                    for (int k = 0; k < K; ++k)
+                        for (int r = 0; r <= k; ++r) {
+                            dr[k] += wd_binom[k][r] * bk[(k - r) * 32 + b] * tr[r];
+                            di[k] += wd_binom[k][r] * bk[(k - r) * 32 + b] * ti[r];
+                        }
+                }
+                double xr = 0.0, xi = 0.0;
+                for (int k = 0; k < K; ++k) {
+                    double cr = cw[((size_t)i * K + k) * 2], ci = -cw[((size_t)i * K + k) * 2 + 1];
+                    xr += dr[k] * cr - di[k] * ci;
+                    xi += dr[k] * ci + di[k] * cr;
+                }
+                acc[2 * i] += xr;
+                acc[2 * i + 1] += xi;
+            }
+        }
+        free(loc);
+    }
+}

@@ -149,9 +149,11 @@ class GridParams:
     lshift: float
     mshift: float
     tile: int = TILE
-    wmode: int = 0        # 0: ES-kernel w-planes (equispaced), 1: polynomial (Chebyshev-node) w-planes
-    wcenter: float = 0.0  # wmode 1: centre of the w range
-    whalf: float = 0.0    # wmode 1: half-width of the w range
+    wmode: int = 0        # 0: ES-kernel w-planes (equispaced), 1: polynomial (Chebyshev-node) w-planes,
+                          # 2: ONE plane, the w-term folded into differentiated gridding kernels (see Plan._init_wd)
+    wcenter: float = 0.0  # wmode 1, 2: centre of the w range
+    whalf: float = 0.0    # wmode 1, 2: half-width of the w range
+    nderiv: int = 0       # wmode 2: number K of kernel functions per axis (phi, phi'', ... phi^(2K-2))
 
     def asdict(self):
         return asdict(self)
@@ -233,10 +235,11 @@ def choose_params(uvw, freq, mask, nx, ny, px, py, center_x, center_y, epsilon, 
         amp2 = (f0 / float(kernel_ft(np.array([0.5 * nx / nu]), r["W"], r["beta"])[0])) * \
                (f0 / float(kernel_ft(np.array([0.5 * ny / nv]), r["W"], r["beta"])[0]))
         ampw = f0 / float(kernel_ft(np.array([0.5 / r["sigma"]]), r["W"], r["beta"])[0])
-        for wmode in ((0, 1) if (do_wgridding and tmax > 0 and force_wmode is None) else
+        for wmode in ((0, 1, 2) if (do_wgridding and tmax > 0 and force_wmode is None) else
                       ((force_wmode,) if (do_wgridding and tmax > 0) else (0,))):
             if force is None and 2.5e-19 * amp2 * (max(ampw, 1.0) if (do_wgridding and tmax > 0 and wmode == 0) else 1.0) > 0.2 * epsilon:
                 continue
+            nder = 0
             if do_wgridding and tmax > 0:
                 if wmode == 0:
                     dw = 0.5 / r["sigma"] / tmax
@@ -244,24 +247,78 @@ def choose_params(uvw, freq, mask, nx, ny, px, py, center_x, center_y, epsilon, 
                     touched = r["W"]
                 else:
                     dw = 1.0
-                    npl = cheb_planes_needed(2.0 * np.pi * 0.5 * (whi - wlo) * tmax, 2.0 * eps_w)
+                    omega = 2.0 * np.pi * 0.5 * (whi - wlo) * tmax
+                    npl = cheb_planes_needed(omega, 2.0 * eps_w)
                     if npl is None:
                         continue
                     touched = npl
+                    if wmode == 2:
+                        # one plane with K = npl kernel functions per axis: phase centre on axis only (t a function of
+                        # l^2 + m^2), 2 <= K <= 4, and the aliases of the differentiated kernels -- amplified by
+                        # ((1 + 2 sigma) l_max)^(2k) against l_max^(2k) -- still inside the row's share
+                        if lshift != 0.0 or mshift != 0.0 or not 2 <= npl <= WD_MAX_K:
+                            continue
+                        if force is None and r.get("eps_sup", r["eps_max"]) * wd_alias_amplification(omega, npl, nu / nx, nv / ny) > eps1:
+                            continue
+                        nder, npl = npl, 1
             else:
                 dw, npl, touched = 1.0, 1, 1
             fftcost = 2.5e-9 * npl * nu * nv * np.log2(nu * nv) / 8.0
             gridcost = 1.2e-9 * nvis * r["W"] ** 2 * touched / 8.0
             cost = fftcost + gridcost
             if best is None or cost < best[0]:
-                best = (cost, r, nu, nv, dw, npl, wmode)
+                best = (cost, r, nu, nv, dw, npl, wmode, nder)
     if best is None:
         raise ValueError(f"no ES kernel reaches epsilon={epsilon} within sigma in [{sigma_min},{sigma_max}]")
-    _, r, nu, nv, dw, npl, wmode = best
+    _, r, nu, nv, dw, npl, wmode, nder = best
     wmin = 0.5 * (wlo + whi) - 0.5 * (npl - 1) * dw if (do_wgridding and wmode == 0) else 0.0
     return GridParams(nu=nu, nv=nv, W=r["W"], beta=r["beta"], sigma=r["sigma"], nplanes=npl, wmin=wmin, dw=dw,
                       nshift=nshift, lshift=lshift, mshift=mshift, wmode=wmode, wcenter=0.5 * (wlo + whi),
-                      whalf=0.5 * (whi - wlo))
+                      whalf=0.5 * (whi - wlo), nderiv=nder)
+
+
+WD_MAX_K = 4
+
+
+def wd_alias_amplification(omega, K, sig_u, sig_v):
+    """wmode 2: factor by which the k-th correction term's aliases exceed the plain kernel's, summed over the terms:
+    the alias of l^(2k) psi(l) at l + L (L = the grid's period, 2 sigma l_max) carries (l + L)^(2k) where the wanted term has
+    l^(2k) <= l_max^(2k), and the term itself is of size omega^k / k!."""
+    from math import factorial
+
+    g = max(1.0 + 2.0 * sig_u, 1.0 + 2.0 * sig_v) ** 2
+    return float(sum((omega * g) ** k / factorial(k) for k in range(K)))
+
+
+def wd_smax(nx, ny, px, py):
+    """Largest l^2 + m^2 over the pixel lattice of an on-axis image (pixel i sits at (i - n // 2) pixsize)."""
+    return ((nx // 2) * px) ** 2 + ((ny // 2) * py) ** 2
+
+
+def wd_nodes(K, smax):
+    """Chebyshev nodes of the first kind on [0, smax], ascending."""
+    return 0.5 * smax * (1.0 - np.cos(np.pi * (2.0 * np.arange(K) + 1.0) / (2.0 * K)))
+
+
+def wd_matrix(K):
+    """M[k, q]: coefficient of (s / smax)^k in the Lagrange basis polynomial of node q (nodes of wd_nodes)."""
+    return np.ascontiguousarray(np.linalg.inv(np.vander(wd_nodes(K, 1.0), K, increasing=True)))
+
+
+def wd_tables(ktab, W, K, alpha):
+    """(K, W, D + 1): the 2k-th derivative of the kernel's piecewise polynomial (x = (a + 1 - W/2 - (z + 1)/2) 2/W, so
+    d^2/dx^2 = W^2 d^2/dz^2), times (-alpha)^k."""
+    D1 = ktab.shape[1]
+    out = np.zeros((K, W, D1))
+    cur = ktab.copy()
+    out[0] = cur
+    for k in range(1, K):
+        nxt = np.zeros_like(cur)
+        for j in range(D1 - 2):
+            nxt[:, j] = cur[:, j + 2] * ((j + 2) * (j + 1))
+        cur = nxt * (W * W)
+        out[k] = cur * (-alpha) ** k
+    return np.ascontiguousarray(out)
 
 
 MAX_CHEB_PLANES = 24
@@ -324,10 +381,14 @@ class Plan:
             wmin_map, xdw = p.wmin, 1.0 / p.dw
             self.wplanes = p.wmin + p.dw * np.arange(p.nplanes)
             self.nodes = None
-        else:
+        elif p.wmode == 1:
             wmin_map, xdw = p.wcenter, (1.0 / p.whalf if p.whalf > 0 else 0.0)
             self.nodes = cheb_nodes(p.nplanes)
             self.wplanes = p.wcenter + p.whalf * self.nodes
+        else:
+            wmin_map, xdw = p.wcenter, (1.0 / p.whalf if p.whalf > 0 else 0.0)
+            self.nodes = None
+            self.wplanes = np.array([p.wcenter])
         lib().pfbo_vismap(i64(self.nrow), i64(self.nchan), ptr(self.uvw), ptr(self.fc), ptr(self.mask),
                           f64(self.signs[0]), f64(self.signs[1]), f64(self.signs[2]), f64(self.px), f64(self.py),
                           i64(p.nu), i64(p.nv), cint(p.W), cint(int(self.do_w)), f64(wmin_map), f64(xdw), ptr(self.pu),
@@ -352,6 +413,8 @@ class Plan:
         self.kdeg = kernel_poly_degree(p.W)
         self._corr = None
         self.t = nm1_image(self.nx, self.ny, self.px, self.py, p.lshift, p.mshift) + p.nshift if self.do_w else None
+        if self.do_w and p.wmode == 2:
+            self._init_wd()
         self.shifting = (p.lshift != 0.0) or (p.mshift != 0.0) or (p.nshift != 0.0)
         if self.shifting:
             ph = self.uvw_l[:, 0] * p.lshift + self.uvw_l[:, 1] * p.mshift + self.uvw_l[:, 2] * p.nshift
@@ -359,6 +422,30 @@ class Plan:
             self.phase = np.exp(2j * np.pi * ph)
         else:
             self.phase = None
+
+    def _init_wd(self):
+        """wmode 2 (one plane; see pfb_oracle.c: pfbo_grid_plane_wd): the K complex coefficients C_k of every visibility and
+        the scaled derivative tables of the kernel polynomial.
+
+        exp(-2 pi i w t(s)) = exp(-2 pi i wc t(s)) E(dw; s), s = l^2 + m^2, dw = w - wc = pw * whalf; E is interpolated in s
+        at K Chebyshev nodes of [0, smax]: E(dw; s) ~ sum_k C_k(dw) (s / smax)^k, C_k = sum_q M[k, q] E(dw; s_q); and
+        (s / smax)^k in the image is D^k on the gridding kernel, D = -(alpha_u d^2/dx^2 + alpha_v d^2/dy^2) / smax,
+        alpha_u = (nu px / (pi W))^2."""
+        p = self.p
+        assert p.lshift == 0.0 and p.mshift == 0.0, "wmode 2 needs the phase centre on axis"
+        K = p.nderiv
+        self.smax = wd_smax(self.nx, self.ny, self.px, self.py)
+        sq = wd_nodes(K, self.smax)
+        tq = -sq / (1.0 + np.sqrt(1.0 - sq)) + p.nshift
+        M = wd_matrix(K)
+        dw = self.pw * p.whalf
+        ph = dw[:, None] * tq[None, :]
+        ph -= np.rint(ph)
+        self.cw = np.ascontiguousarray(np.exp(-2j * np.pi * ph) @ M.T)          # (n, K), gridding direction
+        au = (p.nu * self.px / (np.pi * p.W)) ** 2 / self.smax
+        av = (p.nv * self.py / (np.pi * p.W)) ** 2 / self.smax
+        self.dtab_u = wd_tables(self.ktab, p.W, K, au)
+        self.dtab_v = wd_tables(self.ktab, p.W, K, av)
 
     # -- helpers -------------------------------------------------------
     @property
@@ -436,6 +523,13 @@ class Plan:
 
     def _degrid(self, grid, plane, acc):
         p = self.p
+        if self.do_w and p.wmode == 2:
+            lib().pfbo_degrid_plane_wd(i64(self.ntu * self.ntv), ptr(self.tstart), ptr(self.order), ptr(self.pu),
+                                       ptr(self.pv), ptr(self.iu0), ptr(self.iv0), ptr(self.cw.view(np.float64)),
+                                       cint(p.nderiv), cint(p.W), ptr(self.dtab_u), ptr(self.dtab_v), cint(self.kdeg),
+                                       i64(p.nu), i64(p.nv), cint(p.tile), ptr(grid.view(np.float64)),
+                                       ptr(acc.view(np.float64)))
+            return
         kwv = np.ascontiguousarray(self.plane_weights(plane))
         lib().pfbo_degrid_plane(i64(self.ntu * self.ntv), ptr(self.tstart), ptr(self.order), ptr(self.pu),
                                 ptr(self.pv), ptr(self.iu0), ptr(self.iv0), ptr(kwv), cint(p.W), f64(p.beta),
@@ -446,6 +540,13 @@ class Plan:
         """Scatter one w-plane (pre-FFT grid), exposed for intermediate parity tests."""
         p = self.p
         grid = np.zeros((p.nu, p.nv), dtype=np.complex128)
+        if self.do_w and p.wmode == 2:
+            lib().pfbo_grid_plane_wd(i64(self.ntu * self.ntv), ptr(self.tstart), ptr(self.order), ptr(self.pu),
+                                     ptr(self.pv), ptr(self.iu0), ptr(self.iv0), ptr(self.cw.view(np.float64)),
+                                     ptr(sval.view(np.float64)), cint(p.nderiv), cint(p.W), ptr(self.dtab_u),
+                                     ptr(self.dtab_v), cint(self.kdeg), i64(p.nu), i64(p.nv), cint(p.tile),
+                                     ptr(grid.view(np.float64)))
+            return grid
         kwv = np.ascontiguousarray(self.plane_weights(plane))
         lib().pfbo_grid_plane(i64(self.ntu * self.ntv), ptr(self.tstart), ptr(self.order), ptr(self.pu), ptr(self.pv),
                               ptr(self.iu0), ptr(self.iv0), ptr(kwv), ptr(sval.view(np.float64)), cint(p.W),

@@ -33,12 +33,14 @@
 #include "devcg.hpp"
 #include "eskernel.hpp"
 #include "gridder_kernels_mp.hpp"
+#include "gridder_wd_api.hpp"
 #include "rowfft_api.hpp"
 #include "vismap.hpp"
 
 namespace pfbhip {
 
 constexpr double SPEED_OF_LIGHT = 299792458.0;
+constexpr double pi_const = 3.14159265358979323846;
 
 #define PFB_ROCFFT(expr)                                                                              \
     do {                                                                                              \
@@ -585,7 +587,7 @@ struct pfbhip_gridder {
                d_cfu.bytes() + d_cfv.bytes() + d_cheb.bytes() + d_ktab.bytes() + d_mask.bytes() + d_src.bytes() + d_work.bytes() + d_work_col.bytes() +
                d_grid.bytes() + d_grid2.bytes() + d_sval.bytes() + d_sacc.bytes() + d_vis.bytes() + d_wgt.bytes() + d_swgt.bytes() +
                d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes() + d_gridB.bytes() +
-               d_accT.bytes() + d_occ.bytes() + d_rowmap.bytes() + d_rec.bytes() + d_pval.bytes() + d_kw.bytes() + d_tau.bytes();
+               d_accT.bytes() + d_occ.bytes() + d_rowmap.bytes() + d_rec.bytes() + d_pval.bytes() + d_kw.bytes() + d_tau.bytes() + d_dtab.bytes() + d_cw.bytes();
     }
 
     PlaneArgs plane_args(int plane) const
@@ -692,6 +694,13 @@ struct pfbhip_gridder {
     // of the current apply (kp_max per visibility), written by the gather inside a Hessian apply (pval_ready) or by
     // k_plane_values in front of the scatter
     bool scatter_rec = false, pval_ready = false, want_pval = false;
+    // one-plane w-scheme (info.wmode == 2, gridder_wd_api.hpp): K kernel functions per axis, their derivative tables, the K
+    // complex coefficients of every sorted visibility; d_pval then holds K values per visibility
+    WdArgs wd{};
+    DevBuf<double> d_dtab;
+    DevBuf<double2> d_cw;
+    bool wd_small = false;  // few work items: one scatter launch with the atomic tile flush instead of four colour launches
+    int pval_per_vis() const { return info.wmode == 2 ? wd.K : kp_max; }
     bool pval_from_gather = false;  // single-pass plans: the gather's epilogue writes the scatter's values inside a Hessian apply
     DevBuf<VisRec> d_rec;
     // row-walk gather (k_degrid_rw): same plans as the record scatter; d_kw: plane weights of every visibility (plan time)
@@ -719,7 +728,9 @@ struct pfbhip_gridder {
             const size_t grp = work_off.size() > 1 ? size_t(plane0 / kp_max) : 0;
             if (scatter_rec && !pval_ready) {
                 timer.begin(5);
-                if (prm.do_wgridding && info.wmode == 0)
+                if (info.wmode == 2)
+                    wd_launch_plane_values(wd.K, info.nactive, d_cw.p, sval, d_pval.p, stream);
+                else if (prm.do_wgridding && info.wmode == 0)
                     hipLaunchKernelGGL((k_plane_values_es<W>), dim3(ga.a.nwork), dim3(256), 0, stream, ga, sval, d_pval.p);
                 else
                     hipLaunchKernelGGL((k_plane_values<W>), dim3(uint32_t(ceil_div(info.nactive, 256))), dim3(256), 0, stream, ga,
@@ -731,6 +742,11 @@ struct pfbhip_gridder {
                 ga.a.nwork = uint32_t(col_cnt[grp * 4 + size_t(col)]);
                 if (ga.a.nwork == 0) continue;
                 timer.begin(0);
+                if (info.wmode == 2) {
+                    wd_launch_grid(ga, wd, d_rec.p, d_pval.p, grid_cur, stream);
+                    timer.end();
+                    continue;
+                }
                 if (scatter_rec) {
                     if (stamp_mode == 1 && d_stamps.p != nullptr) ga.dbg = d_stamps.p + (col_off[grp * 4 + size_t(col)]) * 8;
                     switch (kp) {
@@ -797,6 +813,10 @@ struct pfbhip_gridder {
     {
         GroupArgs ga = group_args(plane0, kp);
         if (ga.a.nwork == 0) return;
+        if (info.wmode == 2) {
+            wd_launch_degrid(ga, wd, d_rec.p, grid_cur, sacc, want_pval ? d_swgt.p : nullptr, want_pval ? d_pval.p : nullptr, stream);
+            return;
+        }
         if (gather_rw) {
             switch (kp) {
                 case 1: launch_degrid_rw_wk<W, 1>(ga, sacc); break;
@@ -1111,7 +1131,15 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
     const KernelRow *best = nullptr;
     int64_t bnu = 0, bnv = 0, bnpl = 1;
     double bdw = 1.0;
-    int bmode = 0;
+    int bmode = 0, bnder = 0;
+    // one-plane scheme (wmode 2): phase centre on axis, the record kernels available, not switched off
+    const char *wd_env = std::getenv("PFBHIP_WMODE2");
+    const char *sc_env = std::getenv("PFBHIP_SCATTER");
+    const char *ga_env = std::getenv("PFBHIP_GATHER");
+    const bool wd_allowed = !(wd_env != nullptr && wd_env[0] == '0') && g->info.lshift == 0.0 && g->info.mshift == 0.0 &&
+                            !(sc_env != nullptr && (std::string(sc_env) == "walk" || std::string(sc_env) == "block" ||
+                                                    std::string(sc_env) == "rec_es")) &&
+                            !(ga_env != nullptr && std::string(ga_env) == "walk");
     for (size_t i = 0; i < nrows; ++i) {
         const KernelRow &r = tab[i];
         if (prm.force_W > 0) {
@@ -1151,13 +1179,33 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
             }
             RowFFTPlan tmp;
             const bool own = rowfft_make_plan(nu, &tmp) && rowfft_make_plan(nv, &tmp);
-            for (int mode = 0; mode < (wgrid ? 2 : 1); ++mode) {
+            for (int mode = 0; mode < (wgrid ? 3 : 1); ++mode) {
                 if (wgrid && prm.force_wmode != 0 && prm.force_wmode != mode + 1) continue;
                 if ((wgrid && mode == 0 ? rounding_es : (wgrid ? rounding_poly : rounding_es)) > 0.2 * prm.epsilon) continue;
                 double dw = 1.0;
                 int64_t npl = 1, touched = 1;
+                int nder = 0;
                 if (wgrid) {
-                    if (mode == 0) {
+                    if (mode == 2) {
+                        // ONE plane, K kernel functions per axis (gridder_kernels_wd.hpp): the K of the polynomial scheme --
+                        // the same interpolation bound, in s = l^2 + m^2 instead of w -- while 2 <= K <= 4; the aliases of
+                        // the k-th derivative term carry ((1 + 2 sigma) l_max)^(2k) where the wanted term has <= l_max^(2k)
+                        // at weight omega^k / k!: the row's worst-position error times that sum must still pass
+                        if (!wd_allowed) continue;
+                        const double omega = 2.0 * pi * 0.5 * (whi - wlo) * tmax;
+                        const int K = poly_planes_needed(omega, 2.0 * eps_w);
+                        if (K < 2 || K > WD_MAX_K) continue;
+                        const double gg = std::pow(std::max(1.0 + 2.0 * double(nu) / double(prm.nx), 1.0 + 2.0 * double(nv) / double(prm.ny)), 2);
+                        double amp = 0.0, term = 1.0;
+                        for (int k = 0; k < K; ++k) {
+                            amp += term;
+                            term *= omega * gg / double(k + 1);
+                        }
+                        if (prm.force_W <= 0 && r.eps_sup * amp > eps1) continue;
+                        nder = K;
+                        npl = 1;
+                        touched = K;
+                    } else if (mode == 0) {
                         dw = 0.5 / r.sigma / tmax;  // the w axis keeps the oversampling the kernel row was designed for
                         npl = int64_t((whi - wlo) / dw + r.W);
                         touched = r.W;
@@ -1183,7 +1231,7 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
                 const double own_pt = (nu > 16384 || nv > 16384) ? 3.7e-11 : 2.7e-11;
                 const double plane_cost = own ? own_pt * double(nu) * double(nv)
                                               : 1.2 * (fft2d_seconds(nu, nv) + 3.0 * 16.0 * double(nu) * double(nv) / 5.0e12);
-                const double gridcost = nvis * double(std::min<int64_t>(touched, npl)) * 0.30e-9;
+                const double gridcost = nvis * double(nder > 0 ? touched : std::min<int64_t>(touched, npl)) * 0.30e-9;
                 const double cost = double(npl) * plane_cost + gridcost;
                 // cheapest wins; within 1 % the more accurate row does (W is free up to 16, so the best row
                 // that maps to the same grid and plane count usually beats the requested epsilon)
@@ -1197,10 +1245,14 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
                     bnpl = npl;
                     bdw = dw;
                     bmode = mode;
+                    bnder = nder;
                 }
             }
         }
     }
+    PFB_REQUIRE(best != nullptr || !(wgrid && prm.force_wmode == 3),
+                "force_wmode=2: the one-plane w-scheme needs the phase centre on axis and 2..%d kernel functions for this field "
+                "of view and w range (epsilon=%g); leave the scheme to the plan", WD_MAX_K, prm.epsilon);
     PFB_REQUIRE(best != nullptr || !(wgrid && prm.force_wmode == 2),  // (C-ABI encoding: 0 = plan decides, wmode + 1 otherwise)
                 "force_wmode=1: the polynomial w-plane scheme needs more than %d planes for this field of view and w range "
                 "(epsilon=%g); leave the scheme to the plan", MAX_POLY_PLANES, prm.epsilon);
@@ -1216,6 +1268,7 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
     info.nplanes = bnpl;
     info.dw = bdw;
     info.wmode = bmode;
+    info.nderiv = bnder;
     info.occ_rows = 0;
     info.wcenter = 0.5 * (wlo + whi);
     info.whalf = 0.5 * (whi - wlo);
@@ -1226,6 +1279,8 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
     g->lagr_coef.clear();
     if (bmode == 0) {
         for (int64_t p = 0; p < bnpl; ++p) g->wplanes[size_t(p)] = info.wmin + double(p) * bdw;
+    } else if (bmode == 2) {
+        g->wplanes[0] = info.wcenter;
     } else {
         for (int64_t p = 0; p < bnpl; ++p) g->nodes.push_back(-std::cos(pi * (2.0 * double(p) + 1.0) / (2.0 * double(bnpl))));
         for (int64_t p = 0; p < bnpl; ++p) {
@@ -1450,13 +1505,16 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         // (mean over the passes: the first and last pass of an ES-plane plan hold the few visibilities at the ends of the w
         // range -- their launches are short whichever kernel runs them)
         const size_t per_pass = work.size() / std::max<size_t>(g->work_cnt.size(), 1);
-        if (g->scatter_blk && smode != "block" && smode != "rec" && smode != "rec_es" && per_pass < size_t(2048)) g->scatter_blk = false;
+        if (info.wmode == 2) {
+            PFB_REQUIRE(g->scatter_blk, "the one-plane w-scheme needs the block-ordered sort");
+            g->wd_small = per_pass < size_t(2048);
+        } else if (g->scatter_blk && smode != "block" && smode != "rec" && smode != "rec_es" && per_pass < size_t(2048)) g->scatter_blk = false;
     }
     {
         // colour slices of every group's list (LPT order kept inside a slice); chunks of a tile that has several in the
         // slice are flagged shared (pad = 1) and keep the atomic flush
         const int64_t ntu_c = ceil_div(info.nu, TILE);
-        g->coloured = g->scatter_blk && (ntu_c % 2 == 0) && (m.ntv % 2 == 0) && info.nu % TILE == 0 && info.nv % TILE == 0;
+        g->coloured = g->scatter_blk && !g->wd_small && (ntu_c % 2 == 0) && (m.ntv % 2 == 0) && info.nu % TILE == 0 && info.nv % TILE == 0;
         std::vector<WorkItem> wcol;
         wcol.reserve(work.size());
         g->col_off.clear();
@@ -1488,7 +1546,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             PFB_HIP(hipMemcpyAsync(g->d_work_col.p, wcol.data(), wcol.size() * sizeof(WorkItem), hipMemcpyHostToDevice, st));
         PFB_HIP(hipStreamSynchronize(st));  // wcol is a local
     }
-    const bool rec_mode = info.nplanes <= g->kp_max && (!prm.do_wgridding || info.wmode == 1) && info.nactive > 0 && !work.empty();
+    const bool rec_mode = info.nplanes <= g->kp_max && (!prm.do_wgridding || info.wmode >= 1) && info.nactive > 0 && !work.empty();
     // ES-kernel plane stacks (round 3): the record scatter with the values of each pass written by k_plane_values_es in front of
     // it, ONLY with PFBHIP_SCATTER=rec_es.  Measured (gpurun_out/r03w, r03x): 8192^2 image, 19 planes, 9.5e6 visibilities: scatter
     // 21.2 -> 17.8 ms, + 1.4 ms of plane values (88 bytes per visibility and pass), apply 73.2 -> 70.9 ms; C5: 195 -> 190 ms,
@@ -1499,13 +1557,13 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     g->pval_from_gather = rec_mode && g->scatter_rec;
     {
         const char *genv = std::getenv("PFBHIP_GATHER");
-        g->gather_rw = rec_mode && !(genv != nullptr && std::string(genv) == "walk");
+        g->gather_rw = rec_mode && (info.wmode == 2 || !(genv != nullptr && std::string(genv) == "walk"));
         const char *denv = std::getenv("PFBHIP_RW_DEPTH");
         g->rw_depth = denv != nullptr ? std::max(0, std::min(3, std::atoi(denv))) : 0;
     }
     if (rec_mode || g->scatter_rec) {
         g->d_rec.alloc(size_t(info.nactive) + REC_PAD);
-        g->d_pval.alloc((size_t(info.nactive) + REC_PAD) * size_t(g->kp_max));
+        g->d_pval.alloc((size_t(info.nactive) + REC_PAD) * size_t(info.wmode == 2 ? info.nderiv : g->kp_max));
         PFB_HIP(hipMemsetAsync(g->d_pval.p, 0, g->d_pval.bytes(), st));
         switch (info.W) {
 #define PFB_CASE(w)                                                                                                      \
@@ -1519,7 +1577,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             default: throw std::runtime_error("unsupported kernel support");
         }
         PFB_HIP(hipGetLastError());
-        if (g->gather_rw) {
+        if (g->gather_rw && info.wmode != 2) {
             g->d_kw.alloc((size_t(info.nactive) + REC_PAD) * size_t(g->kp_max));
             // (the planes / polynomial nodes are set by choose_kernel; the work list is not needed here)
             GroupArgs ga = g->group_args(0, int(info.nplanes));
@@ -1569,6 +1627,78 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
                     info.kernel_eps);
         g->d_ktab.alloc(ktab.size());
         PFB_HIP(hipMemcpyAsync(g->d_ktab.p, ktab.data(), ktab.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        if (info.wmode == 2) {
+            // one-plane scheme: derivative tables of the kernel polynomial, interpolation nodes in s, per-visibility coefficients
+            const int K = info.nderiv, W = info.W, D1 = kernel_poly_degree(W) + 1;
+            WdArgs &wa = g->wd;
+            wa = WdArgs{};
+            wa.K = K;
+            wa.W = W;
+            wa.whalf = info.whalf;
+            wa.nshift = info.nshift;
+            std::vector<double> dtab(size_t(K) * W * D1, 0.0);
+            std::copy(ktab.begin(), ktab.end(), dtab.begin());
+            // x = (a + 1 - W/2 - (z + 1) / 2) 2 / W  =>  d^2/dx^2 = W^2 d^2/dz^2
+            for (int k = 1; k < K; ++k)
+                for (int a = 0; a < W; ++a) {
+                    const double *src = &dtab[(size_t(k - 1) * W + a) * D1];
+                    double *dst = &dtab[(size_t(k) * W + a) * D1];
+                    for (int q = 0; q + 2 < D1; ++q) dst[q] = src[q + 2] * double((q + 2) * (q + 1)) * double(W) * double(W);
+                }
+            g->d_dtab.alloc(dtab.size());
+            PFB_HIP(hipMemcpyAsync(g->d_dtab.p, dtab.data(), dtab.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            wa.dtab = g->d_dtab.p;
+            const double xe = double(prm.nx / 2) * prm.pixsize_x, ye = double(prm.ny / 2) * prm.pixsize_y;
+            const double smax = xe * xe + ye * ye;  // largest l^2 + m^2 of the pixel lattice (pixel 0 sits at -(n / 2) pixsize)
+            info.smax = smax;
+            const double au = std::pow(double(info.nu) * prm.pixsize_x / (pi_const * double(W)), 2) / smax;
+            const double av = std::pow(double(info.nv) * prm.pixsize_y / (pi_const * double(W)), 2) / smax;
+            double xq[WD_MAX_K];
+            for (int q = 0; q < K; ++q) {
+                xq[q] = 0.5 * (1.0 - std::cos(pi_const * (2.0 * double(q) + 1.0) / (2.0 * double(K))));  // nodes on [0, 1]
+                const double sq = xq[q] * smax;
+                wa.tq[q] = -sq / (1.0 + std::sqrt(1.0 - sq)) + info.nshift;
+                wa.su[q] = std::pow(-au, q);
+                wa.sv[q] = std::pow(-av, q);
+            }
+            for (int q = 0; q < K; ++q) {  // monomial coefficients of the Lagrange basis polynomial of node q
+                long double c[WD_MAX_K + 1] = {1.0L, 0, 0, 0, 0};
+                int deg = 0;
+                long double den = 1.0L;
+                for (int m2 = 0; m2 < K; ++m2) {
+                    if (m2 == q) continue;
+                    for (int d = deg + 1; d >= 1; --d) c[d] = c[d - 1] - (long double)xq[m2] * c[d];
+                    c[0] = -(long double)xq[m2] * c[0];
+                    ++deg;
+                    den *= (long double)xq[q] - (long double)xq[m2];
+                }
+                for (int k = 0; k < K; ++k) wa.M[k][q] = double(c[k] / den);
+            }
+            g->d_cw.alloc((size_t(info.nactive) + REC_PAD) * size_t(K));
+            wa.cw = g->d_cw.p;
+            wd_launch_coeffs(wa, info.nactive, g->d_pw.p, g->d_cw.p, st);
+            // check the interpolation in s on a dense grid of (dw, s) against the closed form (what the plan promised: 2 eps_w)
+            double worst = 0.0;
+            for (int iw = 0; iw <= 8; ++iw)
+                for (int is = 0; is <= 64; ++is) {
+                    const double dwv = info.whalf * (double(iw) / 4.0 - 1.0), x = double(is) / 64.0, sv_ = x * smax;
+                    const double tt = -sv_ / (1.0 + std::sqrt(1.0 - sv_)) + info.nshift;
+                    double ar = 0.0, ai = 0.0, xp = 1.0;
+                    for (int k = 0; k < K; ++k) {
+                        double cr = 0.0, ci = 0.0;
+                        for (int q = 0; q < K; ++q) {
+                            cr += wa.M[k][q] * std::cos(2.0 * pi_const * dwv * wa.tq[q]);
+                            ci -= wa.M[k][q] * std::sin(2.0 * pi_const * dwv * wa.tq[q]);
+                        }
+                        ar += cr * xp;
+                        ai += ci * xp;
+                        xp *= x;
+                    }
+                    worst = std::max(worst, std::hypot(ar - std::cos(2.0 * pi_const * dwv * tt), ai + std::sin(2.0 * pi_const * dwv * tt)));
+                }
+            if (prm.verbosity > 0) fprintf(stderr, "[pfbhip] one-plane w-scheme: K = %d, interpolation error %.3g\n", K, worst);
+            PFB_REQUIRE(worst <= prm.epsilon, "one-plane w-scheme: interpolation error %g exceeds epsilon %g", worst, prm.epsilon);
+        }
         PFB_HIP(hipStreamSynchronize(st));
     }
 

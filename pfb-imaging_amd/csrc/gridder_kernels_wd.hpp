@@ -1,0 +1,521 @@
+// gridder_kernels_wd.hpp -- scatter / gather of the ONE-PLANE w-scheme (info.wmode == 2, round 4).
+//
+// Narrow fields / near-coplanar arrays (BASELINE C2: omega = 2 pi (w range / 2) max|n - 1| ~ 0.01) used to interpolate the w-term
+// through K = 3 Chebyshev planes in w: three uv-planes scattered, transformed, cropped, padded, transformed and gathered per
+// apply, and the plane transforms were 57 % of it.  The same K-term accuracy is available on ONE plane:
+//
+//     exp(-2 pi i w t(s)) = exp(-2 pi i wc t(s)) * E(dw; s),      s = l^2 + m^2 (phase centre on axis), dw = w - wc
+//     E(dw; s) ~ sum_k C_k(dw) (s / smax)^k                        (Chebyshev interpolation in s at K nodes of [0, smax])
+//     multiplication by l^2 in the image  <->  -(nu px / (pi W))^2 d^2/dx^2 on the u-kernel phi(x)   (exact for the kernel's
+//                                                                                                      own Fourier transform)
+//
+// so the first factor is the w-screen of a single plane at wc (the fused second-axis kernels apply it as before) and the
+// second one goes INTO the gridding kernel of each visibility:
+//
+//     footprint(i, j) = sum_k C_k D^k[phi phi](i, j),   D^k[phi phi] = sum_r binom(k, r) a_r(i) b_{k-r}(j),
+//     a_r = (-alpha_u / smax)^r phi^(2r)(x_i),  b_r = (-alpha_v / smax)^r phi^(2r)(y_j)
+//         = sum_r a_r(i) S_r(j),                S_r(j) = sum_m binom(r + m, r) C_{r+m} b_m(j)            (K complex per column)
+//
+// A cell costs 2 K real FMAs per visibility -- what the K planes cost -- and everything that scaled with the plane count is
+// paid once: LDS tile, accumulator registers, flush, plane clear, four row-FFT kernels.  The derivatives are those of the
+// kernel's piecewise POLYNOMIAL (the function the device evaluates anyway); they enter at relative weight omega^k / k!, so
+// their own accuracy needs are loose (1e-5 / 1e-3 of their size at C2).  Restated on the CPU in oracle/pfb_oracle.c
+// (pfbo_grid_plane_wd / pfbo_degrid_plane_wd) and oracle/wgridder.py (Plan._init_wd); tools/proto_wderiv.py is the numpy
+// prototype against the direct DFT.
+#pragma once
+#include "gridder_wd_api.hpp"
+
+namespace pfbhip {
+
+__host__ __device__ constexpr int wd_binom(int n, int r)
+{
+    return r == 0 || r == n ? 1 : (n == 2 ? 2 : (n == 3 ? 3 : 1));  // n <= 3
+}
+
+// plan time: C_k of every visibility; pw = (w - wcenter) / whalf
+__global__ void k_wd_coeffs(WdArgs wa, int64_t nactive, const double *__restrict__ pw, double2 *__restrict__ cw)
+{
+    const int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (j >= nactive + REC_PAD) return;
+    double er[WD_MAX_K], ei[WD_MAX_K];
+    const double dw = j < nactive ? pw[j] * wa.whalf : 0.0;
+    for (int q = 0; q < wa.K; ++q) {
+        double ph = dw * wa.tq[q];
+        ph -= rint(ph);
+        double s, c;
+        sincospi(-2.0 * ph, &s, &c);
+        er[q] = c;
+        ei[q] = s;
+    }
+    for (int k = 0; k < wa.K; ++k) {
+        double xr = 0.0, xi = 0.0;
+        for (int q = 0; q < wa.K; ++q) {
+            xr = fma(wa.M[k][q], er[q], xr);
+            xi = fma(wa.M[k][q], ei[q], xi);
+        }
+        cw[size_t(j) * size_t(wa.K) + size_t(k)] = j < nactive ? make_double2(xr, xi) : make_double2(0.0, 0.0);
+    }
+}
+
+// per apply (outside Hessian applies): pval[j][k] = sval[j] * C_k(j)
+__global__ void k_plane_values_wd(int K, int64_t nactive, const double2 *__restrict__ cw, const double2 *__restrict__ sval,
+                                  double2 *__restrict__ pval)
+{
+    const int64_t j = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (j >= nactive) return;
+    const double2 v = sval[j];
+    for (int k = 0; k < K; ++k) {
+        const double2 c = cw[size_t(j) * size_t(K) + size_t(k)];
+        pval[size_t(j) * size_t(K) + size_t(k)] = make_double2(v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Scatter: k_grid_rec's structure (one visibility at a time per wave, its (W + 3)^2 block footprint in registers, records
+// and values through scalar loads, three scratch lines round robin) with the K kernel functions.
+//   scratch line (per wave, 3 of them): SU[24][4] then SV[24][4] doubles -- entry t + G holds (a_0 .. a_3)(tap t), zero guards of
+//   G = 3 entries in front and 5 behind; a lane reads whole entries (ds_read_b128 [+ b64 / b128]).
+//   kernel evaluation: round 1 -- lanes 0..15 a_0, 16..31 b_0, 32..47 a_1, 48..63 b_1 (degree D); round 2 (K >= 3) -- a_2, b_2,
+//   a_3, b_3 (degree D - 4), each lane one Horner chain on its own coefficient registers.
+constexpr int WD_LINE = 2 * 24 * 4;  // doubles per scratch line
+constexpr int WD_NLINE = 3;
+__host__ __device__ constexpr int wd_threads() { return 768; }
+__host__ __device__ constexpr size_t wd_lds_doubles(int W, int waves)
+{
+    return size_t(2) * blk_tile_rows(W) * blk_stride(W, 1) + size_t(waves) * WD_NLINE * WD_LINE;
+}
+
+template <int W, int NJ>
+__global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs wa, const VisRec *__restrict__ rec,
+                                                           const double2 *__restrict__ pval, double2 *__restrict__ grid)
+{
+    const PlaneArgs &a = ga.a;
+    constexpr int D = kernel_poly_degree_c(W);
+    constexpr int D2 = D - 4;  // degree of the round-2 chains (4th / 6th derivative)
+    constexpr int LS = blk_stride(W, 1);
+    constexpr int LL = blk_tile_rows(W) * LS;
+    constexpr int FP = W + BLK_CELLS - 1;
+    constexpr int NR = blk_rows_per_lane(W);
+    constexpr int G = BLK_CELLS - 1;
+    constexpr bool SKIP = (FP % 3) == 1;
+    const int BLK_THREADS = int(blockDim.x);
+    extern __shared__ double lds[];
+    double *scr_all = lds + 2 * LL;
+
+    const uint32_t item = blockIdx.x;
+    if (item >= a.nwork) return;
+    const WorkItem wi = a.work[item];
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const uint32_t n = wi.end - wi.begin;
+    const uint32_t NW = uint32_t(BLK_THREADS) / 64;
+    auto share_begin = [&](uint32_t w) {
+        const uint32_t per = NW / 3, cls = min(w / max(per, 1u), 2u), in = w - cls * per;
+        float f = 0.f;
+        for (uint32_t q = 0; q < cls; ++q) f += ga.wshare[q];
+        const uint32_t ncls = cls == 2 ? NW - 2 * per : per;
+        f += ga.wshare[cls] * float(in) / float(max(ncls, 1u));
+        return w >= NW ? n : min(uint32_t(f * float(n)), n);
+    };
+    const uint32_t j0 = wi.begin + share_begin(uint32_t(wave));
+    const uint32_t j1 = wi.begin + share_begin(uint32_t(wave) + 1);
+    const uint32_t nmine = j1 - j0;
+    constexpr uint32_t pbytes = uint32_t(NJ) * 16u;
+    const char *rbase = reinterpret_cast<const char *>(rec);
+    const char *pbase = reinterpret_cast<const char *>(pval);
+    const int role = lane >> 4, b = lane & 15;  // role: 0 u / k = 0, 1 v / k = 0, 2 u / k = 1, 3 v / k = 1 (round 2: k + 2)
+    const char *zptr = rbase + size_t(j0) * 32 + ((role & 1) ? 8 : 0);
+    // per-lane coefficient registers, scaled by (-alpha / smax)^k of the lane's axis
+    double c1[D + 1], c2[D2 + 1];
+    {
+        const int k1 = role >> 1, k2 = 2 + (role >> 1);
+        const double s1 = (role & 1) ? wa.sv[k1] : wa.su[k1];
+        const bool on1 = b < W && k1 < NJ;
+#pragma unroll
+        for (int q = 0; q <= D; ++q) c1[q] = on1 ? wa.dtab[(size_t(k1) * W + b) * (D + 1) + q] * s1 : 0.0;
+        const bool on2 = b < W && k2 < NJ;
+        const double s2 = on2 ? ((role & 1) ? wa.sv[k2] : wa.su[k2]) : 0.0;
+#pragma unroll
+        for (int q = 0; q <= D2; ++q) c2[q] = on2 ? wa.dtab[(size_t(k2 < NJ ? k2 : 0) * W + b) * (D + 1) + q] * s2 : 0.0;
+    }
+    static_assert(REC_PAD >= 63 + 63 + 3, "the warm-up reads one entry per lane up to 63 + 63 past the current visibility");
+    auto touch = [&](uint32_t first) {
+        const uint32_t jt = first + uint32_t(lane);  // (padded arrays: no clamp)
+        const int t0 = *reinterpret_cast<const int *>(rbase + size_t(jt) * 32 + 16);
+        const double t1 = *reinterpret_cast<const double *>(pbase + size_t(jt) * pbytes);
+        return double(t0) + t1;
+    };
+    double warm = touch(j0);
+    double zq[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) zq[u] = *reinterpret_cast<const double *>(zptr + u * 32);
+
+    for (int i = threadIdx.x; i < 2 * LL; i += BLK_THREADS) lds[i] = 0.0;
+    for (int i = threadIdx.x; i < (BLK_THREADS / 64) * WD_NLINE * WD_LINE; i += BLK_THREADS) scr_all[i] = 0.0;
+
+    char *scr = reinterpret_cast<char *>(scr_all + wave * WD_NLINE * WD_LINE);
+    const int g = lane / 20, cc = lane - 20 * g;
+    const bool act = g < 3 && cc < FP;
+    // where this lane writes its kernel values: entry (b + G) of SU (even roles) / SV (odd roles), slot k
+    char *wptr1 = scr + (((role & 1) ? 24 : 0) + b + G) * 32 + (role >> 1) * 8;
+    char *wptr2 = wptr1 + 16;
+    const char *suptr = scr + g * 32;               // + offu + 96 k: entry of row 3 k + g
+    const char *svptr = scr + 24 * 32 + cc * 32;    // + offv: entry of column cc
+    __syncthreads();
+
+    const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
+    const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
+
+    double are[NR], aim[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) are[k] = aim[k] = 0.0;
+
+    char *const tile0 = reinterpret_cast<char *>(lds) + (g * LS + cc) * 8;
+    auto flush = [&](int blk) {
+        const int r0 = (blk >> 8) * BLK_CELLS, c0 = (blk & 255) * BLK_CELLS;
+        char *base = tile0 + (r0 * LS + c0) * 8;
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                if (3 * k + g < FP) {
+                    unsafeAtomicAdd(reinterpret_cast<double *>(base + (3 * k * LS) * 8), are[k]);
+                    unsafeAtomicAdd(reinterpret_cast<double *>(base + (LL + 3 * k * LS) * 8), aim[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) are[k] = aim[k] = 0.0;
+    };
+
+    // two independent half chains (even / odd powers): a single wave can issue them back to back
+    auto chain1 = [&](double z) {
+        const double z2 = z * z;
+        double e = c1[D], o = c1[D - 1];
+#pragma unroll
+        for (int k = D - 2; k >= 0; k -= 2) {
+            e = fma(e, z2, c1[k]);
+            if (k >= 1) o = fma(o, z2, c1[k - 1]);
+        }
+        return fma(o, z, e);
+    };
+    auto chain2 = [&](double z) {
+        const double z2 = z * z;
+        double e = c2[D2], o = c2[D2 - 1];
+#pragma unroll
+        for (int k = D2 - 2; k >= 0; k -= 2) {
+            e = fma(e, z2, c2[k]);
+            if (k >= 1) o = fma(o, z2, c2[k - 1]);
+        }
+        return fma(o, z, e);
+    };
+    static_assert((D & 1) == 0 && (D2 & 1) == 0, "even polynomial degrees assumed");
+    auto stage_a = [&](double z, int line) {
+        *reinterpret_cast<double *>(wptr1 + line * (WD_LINE * 8)) = chain1(z);
+        if constexpr (NJ > 2) *reinterpret_cast<double *>(wptr2 + line * (WD_LINE * 8)) = chain2(z);
+    };
+    if (nmine > 0) stage_a(zq[0], 0);
+    int cur = -1;
+    int4 kq[3];
+    double2 pq[3][NJ];
+    const char *const rwave = rbase + size_t(j0) * 32;
+    const char *const pwave = pbase + size_t(j0) * size_t(pbytes);
+    uint32_t roff = 16u, poff = 0u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        kq[u] = *reinterpret_cast<const int4 *>(rwave + roff);
+#pragma unroll
+        for (int p = 0; p < NJ; ++p) pq[u][p] = *reinterpret_cast<const double2 *>(pwave + poff + p * 16);
+        roff += 32u;
+        poff += pbytes;
+    }
+    kq[2] = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < NJ; ++p) pq[2][p] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        asm volatile("" ::"s"(kq[u].x), "s"(kq[u].y), "s"(kq[u].z));
+#pragma unroll
+        for (int p = 0; p < NJ; ++p) asm volatile("" ::"s"(pq[u][p].x), "s"(pq[u][p].y));
+    }
+    zptr += 3 * 32;
+    if (nmine > 0) cur = kq[0].x;
+    for (uint32_t wb = 0; wb < nmine; wb += 63) {
+        asm volatile("" ::"v"(warm));
+        warm = touch(j0 + wb + 63);
+        const uint32_t wend = min(wb + 63u, nmine);
+        for (uint32_t sb = wb; sb < wend; sb += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (sb + uint32_t(u) >= wend) break;
+                const int ld = (u + 2) % 3, nx = (u + 1) % 3;
+                const double znext = zq[nx];
+                zq[u] = *reinterpret_cast<const double *>(zptr);
+                zptr += 32;
+
+                const int4 rk = kq[u];
+                if (rk.x != cur) {
+                    flush(cur);
+                    cur = rk.x;
+                }
+                // scratch offsets from the first-tap cell (rk.w = (lu << 8) | lv): entry G - du / G - dv
+                const int offu = (G - ((rk.w >> 8) & 3)) * 32, offv = (G - (rk.w & 3)) * 32;
+                double B[NJ];
+                {
+                    const char *sv = svptr + u * (WD_LINE * 8) + offv;
+                    const double2 b01 = *reinterpret_cast<const double2 *>(sv);
+                    B[0] = b01.x;
+                    B[1] = b01.y;
+                    if constexpr (NJ == 3) B[2] = *reinterpret_cast<const double *>(sv + 16);
+                    if constexpr (NJ == 4) {
+                        const double2 b23 = *reinterpret_cast<const double2 *>(sv + 16);
+                        B[2] = b23.x;
+                        B[3] = b23.y;
+                    }
+                }
+                const char *su = suptr + u * (WD_LINE * 8) + offu;
+                double A[NR][NJ];
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const double2 a01 = *reinterpret_cast<const double2 *>(su + 96 * k);
+                    A[k][0] = a01.x;
+                    A[k][1] = a01.y;
+                    if constexpr (NJ == 3) A[k][2] = *reinterpret_cast<const double *>(su + 96 * k + 16);
+                    if constexpr (NJ == 4) {
+                        const double2 a23 = *reinterpret_cast<const double2 *>(su + 96 * k + 16);
+                        A[k][2] = a23.x;
+                        A[k][3] = a23.y;
+                    }
+                }
+                stage_a(znext, nx);  // kernel values of visibility s + 1 -> line nx
+#pragma unroll
+                for (int k = 0; k < NR; ++k)
+#pragma unroll
+                    for (int r = 0; r < NJ; ++r) asm volatile("" : "+v"(A[k][r])::"memory");
+#pragma unroll
+                for (int r = 0; r < NJ; ++r) asm volatile("" : "+v"(B[r])::"memory");
+                kq[ld] = *reinterpret_cast<const int4 *>(rwave + roff);
+#pragma unroll
+                for (int p = 0; p < NJ; ++p) pq[ld][p] = *reinterpret_cast<const double2 *>(pwave + poff + p * 16);
+                roff += 32u;
+                poff += pbytes;
+                __builtin_amdgcn_sched_barrier(0);
+                // S_r = sum_m binom(r + m, r) P_{r+m} b_m  (P = value x C_k: wave-uniform, scalar operands)
+                double sr[NJ], si[NJ];
+#pragma unroll
+                for (int r = 0; r < NJ; ++r) {
+                    sr[r] = pq[u][r].x * B[0];
+                    si[r] = pq[u][r].y * B[0];
+#pragma unroll
+                    for (int m = 1; r + m < NJ; ++m) {
+                        const double bm = double(wd_binom(r + m, r)) * B[m];
+                        sr[r] = fma(pq[u][r + m].x, bm, sr[r]);
+                        si[r] = fma(pq[u][r + m].y, bm, si[r]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    bool on = true;
+                    if (SKIP && k == 0) on = (rk.w & 0x300) != 0x300;
+                    if (SKIP && k == NR - 1) on = (rk.w & 0x300) == 0x300;
+                    if (on) {
+#pragma unroll
+                        for (int r = 0; r < NJ; ++r) {
+                            are[k] = fma(A[k][r], sr[r], are[k]);
+                            aim[k] = fma(A[k][r], si[r], aim[k]);
+                        }
+                    }
+                }
+                asm volatile("" ::"s"(rk.y), "s"(rk.z));
+            }
+        }
+    }
+    asm volatile("" ::"v"(warm));
+    if (cur >= 0) flush(cur);
+    __syncthreads();
+    blk_tile_to_grid<W, 1>(ga, wi, lds, bu, bv, grid);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Gather: k_degrid_rw's row walk (lane b on footprint column (b - lv) mod 16, the u-kernel value broadcast from the lane that
+// evaluated it by v_fmac_f64_dpp row_newbcast) on ONE tile, with K u-kernel functions: T_r(col) = sum_i a_r(i) cell(i, col),
+// then value = sum_col sum_r T_r(col) conj(S_r(col)), S_r from the C_k of the visibility (see the header comment).
+template <int NJ, int I>
+__device__ __forceinline__ void wd_steps(const char *base, const double (&ku)[NJ], double (&tr)[NJ], double (&ti)[NJ])
+{
+    if constexpr (I < 16) {
+        const double2 cell = *reinterpret_cast<const double2 *>(base + size_t(I) * RW_LS * 16);
+#pragma unroll
+        for (int r = 0; r < NJ; ++r) {
+            fmac_row_bcast<I>(tr[r], ku[r], cell.x);
+            fmac_row_bcast<I>(ti[r], ku[r], cell.y);
+        }
+        wd_steps<NJ, I + 1>(base, ku, tr, ti);
+    }
+}
+
+// 1024 threads hold 128 VGPRs each; the three / four coefficient sets of K >= 3 need more: 768 threads (168)
+__host__ __device__ constexpr int wd_gather_threads(int NJ) { return NJ <= 2 ? MP_THREADS : 768; }
+
+template <int W, int NJ>
+__global__ void __launch_bounds__(wd_gather_threads(NJ)) k_degrid_wd(GroupArgs ga, WdArgs wa, const VisRec *__restrict__ rec,
+                                                           const double2 *__restrict__ grid, double2 *__restrict__ sacc,
+                                                           const double *__restrict__ swgt, double2 *__restrict__ pval_out)
+{
+    const PlaneArgs &a = ga.a;
+    constexpr int D = kernel_poly_degree_c(W);
+    constexpr int L = TILE + W - 1;
+    constexpr int LL = RW_LS * RW_LS;
+    extern __shared__ double lds[];
+    double2 *tiles = reinterpret_cast<double2 *>(lds);
+
+    const uint32_t item = blockIdx.x;
+    if (item >= a.nwork) return;
+    const WorkItem wi = a.work[item];
+    const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
+    const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
+    const int NT = int(blockDim.x);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = lane & 15, g = lane >> 4;
+    const uint32_t stride = uint32_t(NT / 64) * 4;
+    const uint32_t jlast = wi.end - 1;
+    uint32_t j = wi.begin + wave * 4 + g;
+    bool valid = j < wi.end;
+    auto load_z = [&](uint32_t jj) { return *reinterpret_cast<const double2 *>(rec + min(jj, jlast)); };
+    auto load_key = [&](uint32_t jj) { return rec[min(jj, jlast)].key; };
+    double2 z = load_z(j);
+    int key = load_key(j);
+    double2 cwv[NJ];
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) cwv[k] = wa.cw[size_t(min(j, jlast)) * NJ + k];
+    {
+        for (int i0 = 0; i0 < LL; i0 += 4 * NT) {  // four loads per thread in flight per round
+            double2 v[4];
+            int idx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + int(threadIdx.x) + q * NT;
+                idx[q] = i;
+                const int ic = min(i, LL - 1);
+                const int la = ic / RW_LS, lb = ic - la * RW_LS;
+                int gu = bu + la, gv = bv + lb;
+                gu = gu >= a.nu ? gu % a.nu : gu;
+                gv = gv >= a.nv ? gv % a.nv : gv;
+                const bool in = i < LL && la < L && lb < L;
+                const double2 t = grid[size_t(gu) * size_t(a.apitch) + size_t(gv)];
+                v[q] = in ? t : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (idx[q] < LL) tiles[idx[q]] = v[q];
+        }
+    }
+    // per-lane coefficient registers of tap b: phi (degree D), phi'' (D - 2), phi'''' (D - 4), phi^(6) (D - 6), unscaled
+    double c0[D + 1], c1[D - 1], c2[NJ > 2 ? D - 3 : 1], c3[NJ > 3 ? D - 5 : 1];
+#pragma unroll
+    for (int q = 0; q <= D; ++q) c0[q] = b < W ? wa.dtab[(size_t(0) * W + b) * (D + 1) + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q <= D - 2; ++q) c1[q] = b < W ? wa.dtab[(size_t(1) * W + b) * (D + 1) + q] : 0.0;
+    if constexpr (NJ > 2) {
+#pragma unroll
+        for (int q = 0; q <= D - 4; ++q) c2[q] = b < W ? wa.dtab[(size_t(2) * W + b) * (D + 1) + q] : 0.0;
+    }
+    if constexpr (NJ > 3) {
+#pragma unroll
+        for (int q = 0; q <= D - 6; ++q) c3[q] = b < W ? wa.dtab[(size_t(3) * W + b) * (D + 1) + q] : 0.0;
+    }
+    auto evens = [](const auto &c, auto deg, double zz) {  // Horner in z^2 on the even / odd coefficients, joined at the end
+        constexpr int DG = decltype(deg)::value;
+        const double z2 = zz * zz;
+        double e = c[DG], o = c[DG - 1];
+#pragma unroll
+        for (int k = DG - 2; k >= 0; k -= 2) {
+            e = fma(e, z2, c[k]);
+            if (k >= 1) o = fma(o, z2, c[k - 1]);
+        }
+        return fma(o, zz, e);
+    };
+    auto kernel_values = [&](double zz, const double *scale, double (&out)[NJ]) {
+        out[0] = evens(c0, std::integral_constant<int, D>{}, zz);
+        out[1] = evens(c1, std::integral_constant<int, D - 2>{}, zz) * scale[1];
+        if constexpr (NJ > 2) out[2] = evens(c2, std::integral_constant<int, D - 4>{}, zz) * scale[2];
+        if constexpr (NJ > 3) out[3] = evens(c3, std::integral_constant<int, D - 6>{}, zz) * scale[3];
+    };
+    const int bsel = (b & 7) < NJ ? (b & 7) : 0;
+    __syncthreads();
+
+    const char *tbase = reinterpret_cast<const char *>(tiles);
+    for (uint32_t jb = wi.begin + wave * 4; jb < wi.end; jb += stride) {
+        const uint32_t jn = j + stride;
+        const bool nvalid = jn < wi.end;
+        const double2 nz = load_z(jn);
+        const int nkey = load_key(jn);
+        double2 ncw[NJ];
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) ncw[k] = wa.cw[size_t(min(jn, jlast)) * NJ + k];
+        {
+            double ku[NJ], kvb[NJ];
+            kernel_values(z.x, wa.su, ku);
+            kernel_values(z.y, wa.sv, kvb);
+            const int lu = key >> 8, lv = key & 255;
+            const int cb = (b - lv) & 15;
+            double B[NJ];
+#pragma unroll
+            for (int r = 0; r < NJ; ++r) B[r] = __shfl(kvb[r], (lane & ~15) + cb);
+            const char *base = tbase + (lu * RW_LS + lv + cb) * 16;
+            double tr[NJ], ti[NJ];
+#pragma unroll
+            for (int r = 0; r < NJ; ++r) tr[r] = ti[r] = 0.0;
+#pragma unroll
+            for (int r = 0; r < NJ; ++r) asm volatile("s_nop 1" : "+v"(ku[r]));  // VALU write -> DPP read needs 2 wait states
+            wd_steps<NJ, 0>(base, ku, tr, ti);
+            // Q_r = conj(S_r), S_r = sum_m binom(r + m, r) C_{r+m} b_m ; value += T_r Q_r
+            double vr = 0.0, vi = 0.0;
+#pragma unroll
+            for (int r = 0; r < NJ; ++r) {
+                double qr = cwv[r].x * B[0], qi = cwv[r].y * B[0];
+#pragma unroll
+                for (int m = 1; r + m < NJ; ++m) {
+                    const double bm = double(wd_binom(r + m, r)) * B[m];
+                    qr = fma(cwv[r + m].x, bm, qr);
+                    qi = fma(cwv[r + m].y, bm, qi);
+                }
+                // (tr + i ti) (qr - i qi)
+                vr = fma(tr[r], qr, vr);
+                vr = fma(ti[r], qi, vr);
+                vi = fma(ti[r], qr, vi);
+                vi = fma(-tr[r], qi, vi);
+            }
+            const bool lo = b < 8;
+            const double keep = lo ? vr : vi, give = lo ? vi : vr;
+            const double tot = half_row_sum(keep + rotn_f64<8>(give));  // lanes 0..7: Re, lanes 8..15: Im
+            const double oth = rotn_f64<8>(tot);                        // the other component
+            if (valid) {
+                if (pval_out != nullptr) {
+                    if ((b & 7) < NJ) {
+                        const double wj = swgt[j];
+                        const double re = (lo ? tot : oth) * wj, im = (lo ? oth : tot) * wj;
+                        double cr = cwv[0].x, ci = cwv[0].y;
+#pragma unroll
+                        for (int k = 1; k < NJ; ++k) {
+                            cr = bsel == k ? cwv[k].x : cr;
+                            ci = bsel == k ? cwv[k].y : ci;
+                        }
+                        double *o = reinterpret_cast<double *>(pval_out + size_t(j) * size_t(NJ) + size_t(bsel));
+                        // ((v * swgt) * C_k): what k_plane_values_wd would form from the weighted model visibility
+                        o[lo ? 0 : 1] = lo ? (re * cr - im * ci) : (re * ci + im * cr);
+                    }
+                } else if ((b & 7) == 0) {
+                    double *o = reinterpret_cast<double *>(sacc + j);
+                    o[lo ? 0 : 1] = tot;
+                }
+            }
+        }
+        j = jn;
+        valid = nvalid;
+        z = nz;
+        key = nkey;
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) cwv[k] = ncw[k];
+    }
+}
+
+}  // namespace pfbhip

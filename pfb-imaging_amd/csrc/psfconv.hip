@@ -111,18 +111,18 @@ struct RealFFT2D {
         stream = st;
         rocfft_setup_once();
         size_t lengths[2] = {size_t(n1), size_t(n0)};
-        rocfft_status st = rocfft_status_success;
+        rocfft_status rst = rocfft_status_success;
         // (rocFFT allocates inside plan creation: on failure the cache of released blocks gives way, once)
         if (!retry_after_cache_flush([&] {
                 if (fwd == nullptr)
-                    st = rocfft_plan_create(&fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                    rst = rocfft_plan_create(&fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
                                             rocfft_precision_double, 2, lengths, 1, nullptr);
-                if (st == rocfft_status_success && inv == nullptr)
-                    st = rocfft_plan_create(&inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                if (rst == rocfft_status_success && inv == nullptr)
+                    rst = rocfft_plan_create(&inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
                                             rocfft_precision_double, 2, lengths, 1, nullptr);
-                return st == rocfft_status_success;
+                return rst == rocfft_status_success;
             }))
-            PFB_ROCFFT(st);
+            PFB_ROCFFT(rst);
         size_t a = 0, b = 0;
         PFB_ROCFFT(rocfft_plan_get_work_buffer_size(fwd, &a));
         PFB_ROCFFT(rocfft_plan_get_work_buffer_size(inv, &b));

@@ -195,7 +195,7 @@ class Gridder:
         i = self.info
         return dict(nu=i["nu"], nv=i["nv"], W=i["W"], beta=i["beta"], sigma=i["sigma"], nplanes=i["nplanes"],
                     wmin=i["wmin"], dw=i["dw"], nshift=i["nshift"], lshift=i["lshift"], mshift=i["mshift"],
-                    tile=i["tile"], wmode=i["wmode"], wcenter=i["wcenter"], whalf=i["whalf"])
+                    tile=i["tile"], wmode=i["wmode"], wcenter=i["wcenter"], whalf=i["whalf"], nderiv=i["nderiv"])
 
     def planes(self):
         w = np.empty(self.info["nplanes"], dtype=np.float64)

@@ -709,3 +709,59 @@ def test_stateless_plan_cache_sees_inplace_edits():
     g.close()
     assert rel(h2, ref) < 1e-12 and rel(h2, h1) > 1e-9
     wg.clear_cache()
+
+
+@pytest.mark.parametrize("K, widen, eps, npix", [(2, 30.0, 1e-4, 64), (3, 130.0, 1e-7, 64), (4, 200.0, 1e-7, 64), (3, 60.0, 1e-9, 96),
+                                                 (3, 16.0, 1e-7, 512)])
+def test_one_plane_w_scheme(K, widen, eps, npix, monkeypatch):
+    """wmode 2 (round 4): ONE uv-plane, the rest of the w-term carried by differentiated gridding kernels
+    (csrc/gridder_kernels_wd.hpp) -- against the direct DFT (epsilon), against its CPU restatement run with the plan's
+    parameters (1e-10), against the polynomial-plane scheme it replaces (epsilon), in both directions and inside the fused
+    Hessian apply; the 512^2 case has enough work items for the four colour launches, the others run the single launch."""
+    c = synth.make_case(2500 if npix < 512 else 60000, 2, npix, zscale=1e-3, seed=5)
+    cell = c["cell"] * widen
+    nx, ny = npix, npix - 4
+    x = np.ascontiguousarray(c["x"][:, :ny])
+    g, kw, mask = gpu_plan(c, npix_x=nx, npix_y=ny, pixsize_x=cell, pixsize_y=cell * 1.1, epsilon=eps, force_wmode=2)
+    assert g.info["wmode"] == 2 and g.info["nplanes"] == 1 and g.info["nderiv"] == K, g.info
+    o = oracle_plan(c, g, kw, mask)
+    d = g.vis2dirty(c["vis"], c["wgt"])
+    assert rel(d, o.vis2dirty(c["vis"], c["wgt"])) < 1e-10
+    sub = dict(pixels=None) if npix < 512 else dict(pixels=(np.arange(0, nx * ny, 37) // ny, np.arange(0, nx * ny, 37) % ny))
+    ref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], c["mask"], nx, ny, cell, cell * 1.1, 0, 0, False, True, False, True,
+                            False, **sub)
+    got = d if npix < 512 else d[sub["pixels"]]
+    assert rel(got, ref) < eps
+    v = g.dirty2vis(x)
+    assert rel(v, o.dirty2vis(x)) < 1e-10
+    rows = None if npix < 512 else np.arange(0, c["uvw"].shape[0], 29)
+    if rows is None:
+        refv = dft.dft_dirty2vis(c["uvw"], c["freq"], x, cell, cell * 1.1, 0, 0, False, True, False, True, False)
+        refv[c["mask"] == 0] = 0
+        assert rel(v, refv) < eps
+    else:
+        refv = dft.dft_dirty2vis(c["uvw"], c["freq"], x, cell, cell * 1.1, 0, 0, False, True, False, True, False, rows=rows,
+                                 chans=np.zeros_like(rows))
+        assert rel(v[rows, 0] * 1.0, refv * c["mask"][rows, 0]) < eps
+    # fused Hessian apply (the gather's epilogue writes the scatter's K values per visibility) == the two halves
+    g.set_weights(c["wgt"])
+    beam = 0.5 + np.random.default_rng(2).random((nx, ny))
+    h = g.hessian(x, beam=beam, eta=0.3, wsum=7.0)
+    mv = g.dirty2vis(beam * x)
+    two = beam * g.vis2dirty(mv, c["wgt"]) / 7.0 + 0.3 * x
+    assert rel(h, two) < 1e-10  # (the model visibilities stay in sorted order on the device: other rounding, same arithmetic)
+    # the scheme it replaces, and the switch that disables it
+    g1, _, _ = gpu_plan(c, npix_x=nx, npix_y=ny, pixsize_x=cell, pixsize_y=cell * 1.1, epsilon=eps, force_wmode=1)
+    assert g1.info["wmode"] == 1 and g1.info["nplanes"] == K
+    assert rel(d, g1.vis2dirty(c["vis"], c["wgt"])) < eps
+    g1.close()
+    g.close()
+    monkeypatch.setenv("PFBHIP_WMODE2", "0")
+    g0, _, _ = gpu_plan(c, npix_x=nx, npix_y=ny, pixsize_x=cell, pixsize_y=cell * 1.1, epsilon=eps)
+    assert g0.info["wmode"] == 1
+    g0.close()
+    monkeypatch.delenv("PFBHIP_WMODE2")
+    # off-axis phase centres keep the polynomial planes
+    g2, _, _ = gpu_plan(c, npix_x=nx, npix_y=ny, pixsize_x=cell, pixsize_y=cell * 1.1, epsilon=eps, center_x=1e-4)
+    assert g2.info["wmode"] in (0, 1)
+    g2.close()

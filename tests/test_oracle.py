@@ -20,6 +20,29 @@ def _case(nrow=2000, nchan=2, npix=48, zscale=0.3, widen=40.0, seed=1):
     return c
 
 
+@pytest.mark.parametrize("K, widen, eps", [(2, 30.0, 1e-4), (3, 130.0, 1e-7), (4, 200.0, 1e-7), (3, 60.0, 1e-9)])
+def test_one_plane_scheme_vs_dft(K, widen, eps):
+    """wmode 2: one uv-plane, the w-term in differentiated gridding kernels (oracle/pfb_oracle.c: pfbo_grid_plane_wd)."""
+    c = synth.make_case(2500, 2, 64, zscale=1e-3, seed=5)
+    cell = c["cell"] * widen
+    plan = owg.Plan(c["uvw"], c["freq"], c["mask"], 64, 60, cell, cell * 1.1, 0.0, 0.0, eps, False, True, False, True, False,
+                    force_wmode=2)
+    assert plan.p.wmode == 2 and plan.p.nplanes == 1 and plan.p.nderiv == K
+    x = c["x"][:, :60]
+    ref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], c["mask"], 64, 60, cell, cell * 1.1, 0, 0, False, True, False,
+                            True, False)
+    assert rel(plan.vis2dirty(c["vis"], c["wgt"]), ref) < eps
+    refv = dft.dft_dirty2vis(c["uvw"], c["freq"], x, cell, cell * 1.1, 0, 0, False, True, False, True, False)
+    refv[c["mask"] == 0] = 0
+    v = plan.dirty2vis(x)
+    assert rel(v, refv) < eps
+    y = c["vis"] * c["mask"]
+    lhs = np.vdot(v, y).real
+    assert abs(lhs - np.vdot(x, plan.vis2dirty(y))) < 1e-12 * abs(lhs)
+    with pytest.raises(ValueError):  # off-axis phase centres are not admissible (t is not a function of l^2 + m^2)
+        owg.Plan(c["uvw"], c["freq"], c["mask"], 64, 60, cell, cell, 0.01, 0.0, eps, False, True, False, True, False, force_wmode=2)
+
+
 @pytest.mark.parametrize("wmode", [0, 1])
 @pytest.mark.parametrize("center", [(0.0, 0.0), (0.01, -0.02)])
 def test_restatement_vs_dft(wmode, center):
@@ -38,10 +61,14 @@ def test_restatement_vs_dft(wmode, center):
 
 
 def test_mode_choice_and_exact_kernel_option():
-    """Narrow fields pick polynomial w-planes (fewer planes than the kernel support), wide fields
-    the ES-kernel planes; the polynomial kernel form agrees with the exact kernel."""
+    """Narrow fields pick polynomial w-planes (fewer planes than the kernel support) -- or, with the phase centre on axis,
+    ONE plane with that many kernel functions --, wide fields the ES-kernel planes; the polynomial kernel form agrees with
+    the exact kernel."""
     narrow = _case(zscale=1e-3, widen=1.0)
     p = owg.Plan(narrow["uvw"], narrow["freq"], narrow["mask"], 48, 48, narrow["cell"], narrow["cell"], epsilon=1e-7,
+                 flip_v=True, divide_by_n=False)
+    assert p.p.wmode == 2 and p.p.nplanes == 1 and 2 <= p.p.nderiv < p.p.W
+    p = owg.Plan(narrow["uvw"], narrow["freq"], narrow["mask"], 48, 48, narrow["cell"], narrow["cell"], 1e-4, 0.0, epsilon=1e-7,
                  flip_v=True, divide_by_n=False)
     assert p.p.wmode == 1 and p.p.nplanes < p.p.W
     wide = _case()
