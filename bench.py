@@ -67,8 +67,10 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
     fused = bool(info.get("fft_mode", 0) & 2)
     tfft = bool(info.get("fft_mode", 0) & 8)
     rec = info.get("scatter_mode", 0) == 2
+    wd = info.get("wmode", 0) == 2           # one plane, K kernel functions per axis: K values / coefficients per visibility
+    K = info.get("nderiv", 0)
     nsl = max(int(info.get("scatter_launches", 1)), 1)
-    vis_rec = 32 + (16 * ppl if rec else 40)  # per visibility and pass: record + values (k_grid_rec) / coordinates + value
+    vis_rec = 32 + (16 * K if wd else (16 * ppl if rec else 40))  # per visibility and pass: record + values / coordinates + value
     # cells of a plane the scatter / gather can touch (tiles with visibilities + halo): what the first-axis transforms and the
     # plane clear move of the occupied rows
     Au = info.get("used_cells", 0) * Sc or occ * G
@@ -76,7 +78,7 @@ def algorithmic_bytes(info, nx, ny, nrow, nactive):
         # used plane cells written (read-add-written by tile) once + the visibility records; one launch per tile colour
         "grid": (ppl * Au + nactive * vis_rec) / nsl,
         # used plane cells read once + records (+ the plane-weighted values it writes inside a Hessian apply)
-        "degrid": ppl * Au + nactive * (32 + 8 * ppl + (16 * ppl if rec else 16)),
+        "degrid": ppl * Au + nactive * ((32 + 16 * K + 8 + 16 * K) if wd else (32 + 8 * ppl + (16 * ppl if rec else 16))),
     }
     launches = {"grid": ngroups * nsl, "degrid": ngroups}
     if fused:
@@ -415,7 +417,7 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
         pmc, pmc_file = {}, None
         import glob
 
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=os.path.getmtime)  # newest by time
         if cands:
             try:
                 pmc = json.load(open(cands[-1]))
@@ -423,11 +425,14 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
             except Exception:
                 pmc = {}
         names = dict(KERNEL_OF)
-        if info["scatter_mode"] != 2:
+        if info["wmode"] == 2:
+            names.update({"grid": "k_grid_wd", "degrid": "k_degrid_wd"})
+        elif info["scatter_mode"] != 2:
             names["grid"] = "k_grid_blk" if info["scatter_mode"] == 1 else "k_grid_mp"
         if not info["fft_mode"] & 8:
             names["fft_rows"] = "k_rowfft_plain"
-        scatter_txt = {2: f"record-driven register footprint (k_grid_rec), {info['scatter_launches']} launch(es) per pass",
+        scatter_txt = {2: (f"record-driven register footprint, {info['nderiv']} kernel functions per axis (k_grid_wd), " if info["wmode"] == 2 else
+                           "record-driven register footprint (k_grid_rec), ") + f"{info['scatter_launches']} launch(es) per pass",
                        1: f"register footprint (k_grid_blk), {info['scatter_launches']} launch(es) per pass",
                        0: "diagonal walk (k_grid_mp)"}[info["scatter_mode"]]
         metric = f"Mvis/s gridded+degridded in exact Hessian applies ({size_txt})" if not solve else \
@@ -451,11 +456,12 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
                 "workload": wl, "bands": 1 if split else world,
                 **({"w_planes_per_rank": planes_per_rank, "split": "contiguous |w| ranges (parallel.partition_rows_by_w), one "
                     "all-reduce of the image per apply"} if split else {}),
-                "w_scheme": "polynomial planes" if info["wmode"] == 1 else "ES-kernel planes",
+                "w_scheme": {0: "ES-kernel planes", 1: "polynomial planes",
+                             2: f"one plane, the w-term in {info['nderiv']} differentiated kernel functions per axis"}[info["wmode"]],
                 "vis_per_band": int(case["uvw"].shape[0] * case["freq"].size), "active_vis_per_band": int(g.nactive),
                 "image": [nx, ny], "epsilon": args.epsilon, "grid": [info["nu"], info["nv"]], "occupied_rows": info["occ_rows"],
                 "w_planes": info["nplanes"], "kernel_support": info["W"], "scatter": scatter_txt,
-                "gather": "row walk, DPP-broadcast FMAs (k_degrid_rw)" if (info["scatter_mode"] == 2 or info["nplanes"] <= 4 and info["wmode"] == 1) else "diagonal walk (k_degrid_mp)",
+                "gather": "row walk, DPP-broadcast FMAs (k_degrid_wd)" if info["wmode"] == 2 else "row walk, DPP-broadcast FMAs (k_degrid_rw)" if (info["scatter_mode"] == 2 or info["nplanes"] <= 4 and info["wmode"] == 1) else "diagonal walk (k_degrid_mp)",
                 "plane_transform": ("own row FFT" if info["fft_mode"] & 1 else "rocFFT rows") +
                 (" with the transposes folded in" if info["fft_mode"] & 8 else "") +
                 (" + fused second axis" if info["fft_mode"] & 2 else
@@ -474,7 +480,9 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
                 # HBM bytes per launch of this stage from the PMC counters: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
                 # this same command (tools/final_profile.sh -> tools/pmc_traffic.py, gfx950 FETCH_SIZE x 2 correction), read from
                 # the newest tracked profile of the default workload; null for other workloads or when no profile is tracked
-                "traffic": pmc.get(dom) if cfg == "C2" and not solve else None, "traffic_profile": pmc_file,
+                # (only a profile taken on the SAME kernel: the file names the kernel of every stage it measured)
+                "traffic": pmc.get(dom) if (cfg == "C2" and not solve and pmc.get("_kernels", {}).get(dom) == names.get(dom)) else None,
+                "traffic_profile": pmc_file if pmc.get("_kernels", {}).get(dom) == names.get(dom) else None,
                 "alg_bytes_per_launch": per_launch[dom], "avg_launch_ms": avg_ms, "launches": dom_calls,
                 "actual_bytes_per_apply": actual,
                 "actual_frac": actual / apply_s / 1e9 / HBM_PEAK_GBS,
@@ -484,6 +492,7 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
                 "apply_frac": b_apply / apply_s / 1e9 / HBM_PEAK_GBS,
                 "apply_frac_note": "SURVEY.md section 8(d) UNPRUNED accounting (every plane row and the full second axis); the "
                                    "pipeline that runs moves actual_bytes_per_apply",
+                "stage_kernels": {s_: names.get(s_, s_) for s_ in per_launch if stages[s_][1]},
                 "stage_ms_per_step": stage_ms,
                 "stage_launches_per_step": stage_launches,
                 "stage_achieved_gbs": {s: round(per_launch[s] / (stages[s][0] / max(stages[s][1], 1) * 1e-3) / 1e9, 1)
@@ -499,7 +508,13 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
             nr = -(-(info["W"] + 3) // 3)
             if info["scatter_mode"] == 2 and (info["W"] + 3) % 3 == 1:
                 nr -= 1
-            f64_ops = nr * (1 + 2 * kp) + 14
+            if info["wmode"] == 2:
+                # K complex FMAs per held cell, the K column sums S_r (K (K + 1) real operations + the binomial multiples),
+                # two rounds of kernel polynomials (degree 12, and 8 for the fourth / sixth derivatives)
+                K = info["nderiv"]
+                f64_ops = nr * 2 * K + (K * (K + 1) + K - 2) + 14 + (9 if K > 2 else 0)
+            else:
+                f64_ops = nr * (1 + 2 * kp) + 14
             nsl = max(int(info["scatter_launches"]), 1)
             clock_ghz = 2.0   # what the chip holds under f64 load (tools/ubench.cpp: clock64 / wall = 1.96 GHz), not the 2.4 GHz peak
             floor_ms = g.nactive * f64_ops * 4 / (256 * 4) / (clock_ghz * 1e9) * 1e3 / nsl   # per launch

@@ -743,6 +743,7 @@ struct pfbhip_gridder {
                 if (ga.a.nwork == 0) continue;
                 timer.begin(0);
                 if (info.wmode == 2) {
+                    if (stamp_mode == 1 && d_stamps.p != nullptr) ga.dbg = d_stamps.p + (col_off[grp * 4 + size_t(col)]) * 8;
                     wd_launch_grid(ga, wd, d_rec.p, d_pval.p, grid_cur, stream);
                     timer.end();
                     continue;
@@ -814,6 +815,7 @@ struct pfbhip_gridder {
         GroupArgs ga = group_args(plane0, kp);
         if (ga.a.nwork == 0) return;
         if (info.wmode == 2) {
+            if (stamp_mode == 2 && d_stamps.p != nullptr) ga.dbg = d_stamps.p;
             wd_launch_degrid(ga, wd, d_rec.p, grid_cur, sacc, want_pval ? d_swgt.p : nullptr, want_pval ? d_pval.p : nullptr, stream);
             return;
         }
@@ -1464,6 +1466,10 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         info.nactive = tstart[size_t(nkeys)];
         lap("tile starts");
         const int64_t P = m.key_planes;
+        // visibilities per work item (PFBHIP_CHUNK, 256..4096): smaller items balance the launch tail, larger ones amortise
+        // the per-item prologue / tile flush
+        uint32_t chunk = CHUNK;
+        if (const char *cenv = std::getenv("PFBHIP_CHUNK")) chunk = uint32_t(std::max(256, std::min(int(CHUNK), std::atoi(cenv))));
         for (int64_t grp = 0; grp < (plane_sorted ? ngroups : 1); ++grp) {
             // planes [q, q + kp) are touched by visibilities whose first plane lies in [q - W + 1, q + kp - 1]
             const int64_t q = grp * g->kp_max, kp = std::min<int64_t>(g->kp_max, info.nplanes - q);
@@ -1472,8 +1478,10 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             const size_t first = work.size();
             for (int64_t t = 0; t < info.ntiles; ++t) {
                 const uint32_t b0 = tstart[size_t(t * P + lo_p)], b1 = tstart[size_t(t * P + hi_p + 1)];
-                for (uint32_t b = b0; b < b1; b += CHUNK)
-                    work.push_back(WorkItem{uint32_t(t), b, std::min<uint32_t>(b + CHUNK, b1), 0});
+                // a tile's visibilities in equal parts of <= chunk (4096 + 904 would leave a short item behind a long one)
+                const uint32_t nt = b1 - b0, parts = (nt + chunk - 1) / chunk;
+                for (uint32_t q = 0; q < parts; ++q)
+                    work.push_back(WorkItem{uint32_t(t), b0 + uint32_t(uint64_t(nt) * q / parts), b0 + uint32_t(uint64_t(nt) * (q + 1) / parts), 0});
             }
             // Longest-processing-time-first: heavy chunks are dispatched first, the many tiny ones of the
             // sparse outer uv-plane fill the tail (the uv density is strongly peaked at the centre).

@@ -216,13 +216,13 @@ __host__ __device__ constexpr int blk_stride(int W, int KP)
 
 // Tile -> uv-grid of the register-footprint scatters (k_grid_blk, k_grid_rec); every thread of the workgroup calls it
 // after the barrier that ends the visibility loop.
-template <int W, int KP>
+template <int W, int KP, int LSO = 0>
 __device__ __forceinline__ void blk_tile_to_grid(const GroupArgs &ga, const WorkItem &wi, const double *lds, int bu, int bv,
                                                  double2 *__restrict__ grid)
 {
     const PlaneArgs &a = ga.a;
     constexpr int L = TILE + W - 1;
-    constexpr int LS = blk_stride(W, KP);
+    constexpr int LS = LSO ? LSO : blk_stride(W, KP);  // (LSO: the caller's own tile stride)
     constexpr int LL = blk_tile_rows(W) * LS;
     const int BLK_THREADS = int(blockDim.x);
     // Tile -> uv-grid.  The (TILE + W - 1)^2 regions of tiles two apart in each direction are disjoint (W - 1 < TILE), so

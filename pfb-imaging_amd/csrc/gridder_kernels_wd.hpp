@@ -73,16 +73,24 @@ __global__ void k_plane_values_wd(int K, int64_t nactive, const double2 *__restr
 // ---------------------------------------------------------------------------------------------------------
 // Scatter: k_grid_rec's structure (one visibility at a time per wave, its (W + 3)^2 block footprint in registers, records
 // and values through scalar loads, three scratch lines round robin) with the K kernel functions.
-//   scratch line (per wave, 3 of them): SU[24][4] then SV[24][4] doubles -- entry t + G holds (a_0 .. a_3)(tap t), zero guards of
-//   G = 3 entries in front and 5 behind; a lane reads whole entries (ds_read_b128 [+ b64 / b128]).
+//   scratch line (per wave, 3 of them): SU[22][4] then SV[22][4] doubles -- entry t + G holds (a_0 .. a_3)(tap t), zero guards of
+//   G = 3 entries in front and behind; a lane reads whole entries (ds_read_b128 [+ b64 / b128]).
+//   Workgroup size (round 4, measured on C2): 256 threads -- one wave per SIMD --, three workgroups per CU: the same 12 waves as
+//   one 768-thread workgroup, but a workgroup's prologue (10 k cycles), its wait for the slowest wave and its tile flush overlap
+//   the other two's visibility loops.  (384 threads x 2 was SLOWER than 768 x 1: six waves do not spread evenly over four
+//   SIMDs, and at 3 waves per SIMD by registers the second workgroup does not fit beside the first.)  The LDS budget of three
+//   workgroups is what sets the tile stride (the region's edge rounded up to odd) and the 22-entry scratch arrays.
 //   kernel evaluation: round 1 -- lanes 0..15 a_0, 16..31 b_0, 32..47 a_1, 48..63 b_1 (degree D); round 2 (K >= 3) -- a_2, b_2,
 //   a_3, b_3 (degree D - 4), each lane one Horner chain on its own coefficient registers.
-constexpr int WD_LINE = 2 * 24 * 4;  // doubles per scratch line
+constexpr int WD_ENT = 22;               // entries per scratch array: G + 16 taps + G
+constexpr int WD_LINE = 2 * WD_ENT * 4;  // doubles per scratch line
 constexpr int WD_NLINE = 3;
-__host__ __device__ constexpr int wd_threads() { return 768; }
+__host__ __device__ constexpr int wd_threads() { return 768; }  // register budget: 768 threads per CU (168 VGPRs), as 1 x 768 or 3 x 256
+// tile stride: odd, >= the region's edge (an even stride puts two of a flush's three rows on the same banks)
+__host__ __device__ constexpr int wd_stride(int W) { return (TILE + W - 1) | 1; }
 __host__ __device__ constexpr size_t wd_lds_doubles(int W, int waves)
 {
-    return size_t(2) * blk_tile_rows(W) * blk_stride(W, 1) + size_t(waves) * WD_NLINE * WD_LINE;
+    return size_t(2) * blk_tile_rows(W) * wd_stride(W) + size_t(waves) * WD_NLINE * WD_LINE + 64;  // (+ slack for the idle lanes' reads)
 }
 
 template <int W, int NJ>
@@ -92,7 +100,7 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
     const PlaneArgs &a = ga.a;
     constexpr int D = kernel_poly_degree_c(W);
     constexpr int D2 = D - 4;  // degree of the round-2 chains (4th / 6th derivative)
-    constexpr int LS = blk_stride(W, 1);
+    constexpr int LS = wd_stride(W);
     constexpr int LL = blk_tile_rows(W) * LS;
     constexpr int FP = W + BLK_CELLS - 1;
     constexpr int NR = blk_rows_per_lane(W);
@@ -104,11 +112,15 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
 
     const uint32_t item = blockIdx.x;
     if (item >= a.nwork) return;
+    const bool stamp = ga.dbg != nullptr;
+    const unsigned long long ts0 = stamp ? __builtin_readcyclecounter() : 0ull;
     const WorkItem wi = a.work[item];
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t n = wi.end - wi.begin;
     const uint32_t NW = uint32_t(BLK_THREADS) / 64;
     auto share_begin = [&](uint32_t w) {
+        // (workgroups of one wave per SIMD: no age classes inside the workgroup, equal shares)
+        if (NW % 3 != 0) return w >= NW ? n : uint32_t((uint64_t(n) * w) / NW);
         const uint32_t per = NW / 3, cls = min(w / max(per, 1u), 2u), in = w - cls * per;
         float f = 0.f;
         for (uint32_t q = 0; q < cls; ++q) f += ga.wshare[q];
@@ -156,10 +168,10 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
     const int g = lane / 20, cc = lane - 20 * g;
     const bool act = g < 3 && cc < FP;
     // where this lane writes its kernel values: entry (b + G) of SU (even roles) / SV (odd roles), slot k
-    char *wptr1 = scr + (((role & 1) ? 24 : 0) + b + G) * 32 + (role >> 1) * 8;
+    char *wptr1 = scr + (((role & 1) ? WD_ENT : 0) + b + G) * 32 + (role >> 1) * 8;
     char *wptr2 = wptr1 + 16;
     const char *suptr = scr + g * 32;               // + offu + 96 k: entry of row 3 k + g
-    const char *svptr = scr + 24 * 32 + cc * 32;    // + offv: entry of column cc
+    const char *svptr = scr + WD_ENT * 32 + cc * 32;  // + offv: entry of column cc
     __syncthreads();
 
     const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
@@ -212,6 +224,7 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
         *reinterpret_cast<double *>(wptr1 + line * (WD_LINE * 8)) = chain1(z);
         if constexpr (NJ > 2) *reinterpret_cast<double *>(wptr2 + line * (WD_LINE * 8)) = chain2(z);
     };
+    const unsigned long long ts1 = stamp ? __builtin_readcyclecounter() : 0ull;
     if (nmine > 0) stage_a(zq[0], 0);
     int cur = -1;
     int4 kq[3];
@@ -330,8 +343,27 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
     }
     asm volatile("" ::"v"(warm));
     if (cur >= 0) flush(cur);
+    const unsigned long long ts2 = stamp ? __builtin_readcyclecounter() : 0ull;
     __syncthreads();
-    blk_tile_to_grid<W, 1>(ga, wi, lds, bu, bv, grid);
+    const unsigned long long ts3 = stamp ? __builtin_readcyclecounter() : 0ull;
+    blk_tile_to_grid<W, 1, LS>(ga, wi, lds, bu, bv, grid);
+    if (stamp) {  // PFBHIP_STAMP=1: phase stamps (tools/stamp_scatter.py), the layout of k_grid_rec
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts4 = __builtin_readcyclecounter();
+        unsigned long long *d = ga.dbg + size_t(item) * 8;
+        if (threadIdx.x == 0) {
+            d[0] = ts1 - ts0;
+            d[1] = ts2 - ts1;
+            d[2] = ts3 - ts2;
+            d[3] = ts4 - ts3;
+            d[4] = n;
+            d[7] = wi.tile;
+        }
+        if (threadIdx.x == uint32_t(BLK_THREADS) - 64) {
+            d[5] = ts2 - ts1;
+            d[6] = ts3 - ts2;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -352,8 +384,10 @@ __device__ __forceinline__ void wd_steps(const char *base, const double (&ku)[NJ
     }
 }
 
-// 1024 threads hold 128 VGPRs each; the three / four coefficient sets of K >= 3 need more: 768 threads (168)
-__host__ __device__ constexpr int wd_gather_threads(int NJ) { return NJ <= 2 ? MP_THREADS : 768; }
+// register budget of the gather: 768 threads per CU (168 VGPRs: the three / four coefficient sets of K >= 3 do not fit the 128 of
+// 1024 threads), launched as three workgroups of 256 (one wave per SIMD each: a workgroup's tile load -- 19 % of an item's
+// cycles -- overlaps the other two's rounds; C2: 1.90 -> 1.64 ms)
+__host__ __device__ constexpr int wd_gather_threads(int) { return 768; }
 
 template <int W, int NJ>
 __global__ void __launch_bounds__(wd_gather_threads(NJ)) k_degrid_wd(GroupArgs ga, WdArgs wa, const VisRec *__restrict__ rec,
@@ -369,6 +403,8 @@ __global__ void __launch_bounds__(wd_gather_threads(NJ)) k_degrid_wd(GroupArgs g
 
     const uint32_t item = blockIdx.x;
     if (item >= a.nwork) return;
+    const bool stamp = ga.dbg != nullptr;
+    const unsigned long long ts0 = stamp ? __builtin_readcyclecounter() : 0ull;
     const WorkItem wi = a.work[item];
     const int bu = int(wi.tile / uint32_t(a.ntv)) * TILE;
     const int bv = int(wi.tile % uint32_t(a.ntv)) * TILE;
@@ -441,6 +477,7 @@ __global__ void __launch_bounds__(wd_gather_threads(NJ)) k_degrid_wd(GroupArgs g
     };
     const int bsel = (b & 7) < NJ ? (b & 7) : 0;
     __syncthreads();
+    const unsigned long long ts1 = stamp ? __builtin_readcyclecounter() : 0ull;
 
     const char *tbase = reinterpret_cast<const char *>(tiles);
     for (uint32_t jb = wi.begin + wave * 4; jb < wi.end; jb += stride) {
@@ -515,6 +552,23 @@ __global__ void __launch_bounds__(wd_gather_threads(NJ)) k_degrid_wd(GroupArgs g
         key = nkey;
 #pragma unroll
         for (int k = 0; k < NJ; ++k) cwv[k] = ncw[k];
+    }
+    if (stamp) {  // PFBHIP_STAMP=2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts2 = __builtin_readcyclecounter();
+        unsigned long long *d = ga.dbg + size_t(item) * 8;
+        if (threadIdx.x == 0) {
+            d[0] = ts1 - ts0;
+            d[1] = ts2 - ts1;
+            d[2] = 0;
+            d[3] = 0;
+            d[4] = wi.end - wi.begin;
+            d[7] = wi.tile;
+        }
+        if (threadIdx.x == uint32_t(NT) - 64) {
+            d[5] = ts2 - ts1;
+            d[6] = ts2 - ts0;
+        }
     }
 }
 

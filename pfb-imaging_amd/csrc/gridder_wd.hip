@@ -2,18 +2,39 @@
 // 13 kernel supports x 3 term counts x 2 kernels compile next to gridder.hip, not behind it.
 #include "gridder_kernels_wd.hpp"
 
+#include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "common.hpp"
 
 namespace pfbhip {
 
-int wd_scatter_threads() { return wd_threads(); }
+// Threads per workgroup: 256 -- one wave per SIMD, three workgroups per CU (see gridder_kernels_wd.hpp); PFBHIP_WD_SCATTER_THREADS /
+// PFBHIP_WD_GATHER_THREADS override (measured on C2, ms per apply: scatter 768 x 1: 2.76, 384 x 2: 3.3, 256 x 3: 2.31; gather
+// 768 x 1: 1.90, 384 x 2: 2.33, 256 x 3: 1.64).
+static int env_threads(const char *name, int dflt, int cap)
+{
+    const char *e = std::getenv(name);
+    if (e == nullptr) return dflt;
+    const int v = std::atoi(e);
+    return (v >= 64 && v <= cap && v % 64 == 0) ? v : dflt;
+}
+int wd_scatter_threads()
+{
+    static const int t = env_threads("PFBHIP_WD_SCATTER_THREADS", 256, wd_threads());
+    return t;
+}
+static int wd_gather_threads_rt(int NJ)
+{
+    static const int t = env_threads("PFBHIP_WD_GATHER_THREADS", 256, MP_THREADS);
+    return std::min(t, wd_gather_threads(NJ));
+}
 size_t wd_scatter_lds_bytes(int W)
 {
     size_t n = 0;
     switch (W) {
-#define PFB_CASE(w) case w: n = wd_lds_doubles(w, wd_threads() / 64); break;
+#define PFB_CASE(w) case w: n = wd_lds_doubles(w, wd_scatter_threads() / 64); break;
         PFB_CASE(4) PFB_CASE(5) PFB_CASE(6) PFB_CASE(7) PFB_CASE(8) PFB_CASE(9) PFB_CASE(10) PFB_CASE(11)
         PFB_CASE(12) PFB_CASE(13) PFB_CASE(14) PFB_CASE(15) PFB_CASE(16)
 #undef PFB_CASE
@@ -41,8 +62,8 @@ template <int W, int NJ>
 static void grid_wk(const GroupArgs &ga, const WdArgs &wa, const VisRec *rec, const double2 *pval, double2 *grid, hipStream_t st)
 {
     allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_wd<W, NJ>), 160 * 1024);
-    const size_t lds = wd_lds_doubles(W, wd_threads() / 64) * sizeof(double);
-    hipLaunchKernelGGL((k_grid_wd<W, NJ>), dim3(ga.a.nwork), dim3(wd_threads()), lds, st, ga, wa, rec, pval, grid);
+    const size_t lds = wd_lds_doubles(W, wd_scatter_threads() / 64) * sizeof(double);
+    hipLaunchKernelGGL((k_grid_wd<W, NJ>), dim3(ga.a.nwork), dim3(wd_scatter_threads()), lds, st, ga, wa, rec, pval, grid);
 }
 template <int W>
 static void grid_w(const GroupArgs &ga, const WdArgs &wa, const VisRec *rec, const double2 *pval, double2 *grid, hipStream_t st)
@@ -72,7 +93,7 @@ static void degrid_wk(const GroupArgs &ga, const WdArgs &wa, const VisRec *rec, 
                       const double *swgt, double2 *pval_out, hipStream_t st)
 {
     allow_dynamic_lds(reinterpret_cast<const void *>(&k_degrid_wd<W, NJ>), 160 * 1024);
-    hipLaunchKernelGGL((k_degrid_wd<W, NJ>), dim3(ga.a.nwork), dim3(wd_gather_threads(NJ)), wd_gather_lds_bytes(), st, ga, wa, rec, grid, sacc,
+    hipLaunchKernelGGL((k_degrid_wd<W, NJ>), dim3(ga.a.nwork), dim3(wd_gather_threads_rt(NJ)), wd_gather_lds_bytes(), st, ga, wa, rec, grid, sacc,
                        swgt, pval_out);
 }
 template <int W>

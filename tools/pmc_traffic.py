@@ -48,6 +48,7 @@ def main():
     out = {}
     for s in fetch:
         out[s] = (2.0 * fetch[s] + write.get(s, 0.0)) * 1024.0 / (per_step[s] * applies)
+    out["_kernels"] = bench.get("roofline", {}).get("stage_kernels", {})  # the kernel each stage timer bracketed in that run
     out["_note"] = ("HBM bytes per stage launch = (2*FETCH_SIZE + WRITE_SIZE) KiB / (stage launches per apply x applies), "
                     "rocprofv3 --pmc in two separate passes; gfx950 FETCH_SIZE x2 correction applied (upper bound)")
     json.dump(out, open(sys.argv[4], "w"), indent=1)

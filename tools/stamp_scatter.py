@@ -38,7 +38,7 @@ names = ["prologue", "vis loop (wave 0)", "barrier wait (wave 0)", "tile flush"]
 for i, name in enumerate(names):
     print(f"  {name:24s} {b[:, i].sum() / tot.sum() * 100:5.1f} %   mean {b[:, i].mean():9.0f} cycles")
 print(f"  last wave loop mean {b[:, 5].mean():9.0f}, wait / total {b[:, 6].mean():9.0f}")
-nw = 12 if os.environ["PFBHIP_STAMP"] == "1" else 16
+nw = 12 if (os.environ["PFBHIP_STAMP"] == "1" or g.info["wmode"] == 2) else 16
 print(f"  vis per item mean {b[:, 4].mean():.0f}; cycles per visibility of a wave's share: "
       f"{(b[:, 1] / np.maximum(b[:, 4] / nw, 1)).mean():.0f} (mean over items), "
       f"{b[:, 1].sum() / (b[:, 4].sum() / nw):.0f} (weighted)")
