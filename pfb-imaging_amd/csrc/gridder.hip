@@ -1515,7 +1515,9 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         const size_t per_pass = work.size() / std::max<size_t>(g->work_cnt.size(), 1);
         if (info.wmode == 2) {
             PFB_REQUIRE(g->scatter_blk, "the one-plane w-scheme needs the block-ordered sort");
-            g->wd_small = per_pass < size_t(2048);
+            // (PFBHIP_WD_COLOURS=1: the four colour launches whatever the size -- tests)
+            const char *cenv = std::getenv("PFBHIP_WD_COLOURS");
+            g->wd_small = per_pass < size_t(2048) && !(cenv != nullptr && cenv[0] == '1');
         } else if (g->scatter_blk && smode != "block" && smode != "rec" && smode != "rec_es" && per_pass < size_t(2048)) g->scatter_blk = false;
     }
     {

@@ -216,7 +216,8 @@ __host__ __device__ constexpr int blk_stride(int W, int KP)
 
 // Tile -> uv-grid of the register-footprint scatters (k_grid_blk, k_grid_rec); every thread of the workgroup calls it
 // after the barrier that ends the visibility loop.
-template <int W, int KP, int LSO = 0>
+// MINT: the smallest workgroup the caller launches (sizes the per-thread cell arrays of the plain flush)
+template <int W, int KP, int LSO = 0, int MINT = 512>
 __device__ __forceinline__ void blk_tile_to_grid(const GroupArgs &ga, const WorkItem &wi, const double *lds, int bu, int bv,
                                                  double2 *__restrict__ grid)
 {
@@ -252,7 +253,7 @@ __device__ __forceinline__ void blk_tile_to_grid(const GroupArgs &ga, const Work
     }
     // all loads of the thread's cells first (a load -> add -> store chain per cell would expose the HBM latency once per
     // cell: ~9 cells per thread), then the stores
-    constexpr int NJ = (L * L + 511) / 512;  // cells per thread and plane at the smallest workgroup
+    constexpr int NJ = (L * L + MINT - 1) / MINT;  // cells per thread and plane at the smallest workgroup
     size_t off[NJ];
     int lo[NJ];
 #pragma unroll

@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
     const unsigned long long ts2 = stamp ? __builtin_readcyclecounter() : 0ull;
     __syncthreads();
     const unsigned long long ts3 = stamp ? __builtin_readcyclecounter() : 0ull;
-    blk_tile_to_grid<W, 1, LS>(ga, wi, lds, bu, bv, grid);
+    blk_tile_to_grid<W, 1, LS, 256>(ga, wi, lds, bu, bv, grid);
     if (stamp) {  // PFBHIP_STAMP=1: phase stamps (tools/stamp_scatter.py), the layout of k_grid_rec
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long ts4 = __builtin_readcyclecounter();

@@ -18,7 +18,7 @@ static int env_threads(const char *name, int dflt, int cap)
     const char *e = std::getenv(name);
     if (e == nullptr) return dflt;
     const int v = std::atoi(e);
-    return (v >= 64 && v <= cap && v % 64 == 0) ? v : dflt;
+    return (v >= 256 && v <= cap && v % 64 == 0) ? v : dflt;  // (>= 256: the tile flush holds its cells in registers, sized for that)
 }
 int wd_scatter_threads()
 {

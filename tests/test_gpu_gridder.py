@@ -728,10 +728,13 @@ def test_one_plane_w_scheme(K, widen, eps, npix, monkeypatch):
     Hessian apply; the 512^2 case has enough work items for the four colour launches, the others run the single launch."""
     c = synth.make_case(2500 if npix < 512 else 60000, 2, npix, zscale=1e-3, seed=5)
     cell = c["cell"] * widen
+    if npix >= 512:
+        monkeypatch.setenv("PFBHIP_WD_COLOURS", "1")  # the benchmark's four colour launches (plain tile flush) at a test's size
     nx, ny = npix, npix - 4
     x = np.ascontiguousarray(c["x"][:, :ny])
     g, kw, mask = gpu_plan(c, npix_x=nx, npix_y=ny, pixsize_x=cell, pixsize_y=cell * 1.1, epsilon=eps, force_wmode=2)
     assert g.info["wmode"] == 2 and g.info["nplanes"] == 1 and K <= g.info["nderiv"] <= 4, g.info
+    assert g.info["scatter_launches"] == (4 if npix >= 512 else 1)
     K = g.info["nderiv"]
     o = oracle_plan(c, g, kw, mask)
     d = g.vis2dirty(c["vis"], c["wgt"])
