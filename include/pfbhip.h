@@ -244,6 +244,18 @@ int pfbhip_psfconv_apply(pfbhip_psfconv *p, const double *x_host, int64_t psf_sl
 int pfbhip_psfconv_apply_dev(pfbhip_psfconv *p, const double *x_dev, int64_t psf_slot, int64_t beam_slot, int mode,
                              double shift, double scale, double eta, int accumulate, double *out_dev);
 
+/* Single-precision host arrays: the reference's precision="single" (vis2im / im2vis, operators/gridder.py:58-100:
+ * complex64 visibilities, float32 weights and images) with double-precision accumulation (ducc0's
+ * double_precision_accumulation=True, the reference's default, core/grid.py:50-52).  Values cross PCIe as float / complex64
+ * -- half the bytes of the double entry points, which is what bounds the host-array surface -- and are widened / narrowed on
+ * the device; every device buffer and every sum stays double. */
+int pfbhip_gridder_vis2dirty_sp(pfbhip_gridder *g, const float *vis_host /* (nrow,nchan,2) */,
+                                const float *wgt_host /* (nrow,nchan) or NULL */, float *dirty_host /* (nx,ny) */);
+int pfbhip_gridder_dirty2vis_sp(pfbhip_gridder *g, const float *dirty_host, const float *wgt_host, float *vis_host);
+int pfbhip_gridder_set_weights_sp(pfbhip_gridder *g, const float *wgt_host);
+int pfbhip_gridder_hessian_sp(pfbhip_gridder *g, const float *x_host, const float *beam_host /* or NULL */, double eta,
+                              double wsum, float *out_host);
+
 /* ---- on-device conjugate gradients ------------------------------------- */
 /*
  * Whole-solve entry points: every CG vector stays in HBM, one host call per solve

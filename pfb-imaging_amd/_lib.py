@@ -73,6 +73,7 @@ SYMBOLS = (
     "pfbhip_gridder_get_planes",
     "pfbhip_gridder_vis2dirty", "pfbhip_gridder_vis2dirty_dev", "pfbhip_gridder_dirty2vis", "pfbhip_gridder_grid_plane",
     "pfbhip_gridder_set_weights", "pfbhip_gridder_hessian", "pfbhip_gridder_hessian_dev",
+    "pfbhip_gridder_vis2dirty_sp", "pfbhip_gridder_dirty2vis_sp", "pfbhip_gridder_set_weights_sp", "pfbhip_gridder_hessian_sp",
     "pfbhip_gridder_degrid_dev", "pfbhip_gridder_grid_dev", "pfbhip_gridder_profile", "pfbhip_gridder_profile_get",
     "pfbhip_gridder_debug_stamps",
     "pfbhip_gridder_cg", "pfbhip_gridder_cg_dev",

@@ -439,6 +439,19 @@ __global__ void k_crop_screen_T(ImgGeom g, FusedGeom fg, const double2 *B, int d
 // the handle
 // ---------------------------------------------------------------------------------------
 
+// single-precision I/O (the reference's precision="single" with double_precision_accumulation: values cross PCIe as
+// float / complex64, every sum is formed in double): element-wise widening / narrowing on the device
+__global__ void k_widen_f32(int64_t n, const float *__restrict__ in, double *__restrict__ out)
+{
+    const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i < n) out[i] = double(in[i]);
+}
+__global__ void k_narrow_f64(int64_t n, const double *__restrict__ in, float *__restrict__ out)
+{
+    const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i < n) out[i] = float(in[i]);
+}
+
 struct StageTimer {
     bool enabled = false;
     hipStream_t stream = nullptr;
@@ -587,7 +600,7 @@ struct pfbhip_gridder {
                d_cfu.bytes() + d_cfv.bytes() + d_cheb.bytes() + d_ktab.bytes() + d_mask.bytes() + d_src.bytes() + d_work.bytes() + d_work_col.bytes() +
                d_grid.bytes() + d_grid2.bytes() + d_sval.bytes() + d_sacc.bytes() + d_vis.bytes() + d_wgt.bytes() + d_swgt.bytes() +
                d_img.bytes() + d_img2.bytes() + d_beam.bytes() + d_fftwork.bytes() + d_gridB.bytes() +
-               d_accT.bytes() + d_occ.bytes() + d_rowmap.bytes() + d_rec.bytes() + d_pval.bytes() + d_kw.bytes() + d_tau.bytes() + d_dtab.bytes() + d_cw.bytes();
+               d_accT.bytes() + d_occ.bytes() + d_rowmap.bytes() + d_rec.bytes() + d_pval.bytes() + d_kw.bytes() + d_tau.bytes() + d_dtab.bytes() + d_cw.bytes() + d_stage32.bytes();
     }
 
     PlaneArgs plane_args(int plane) const
@@ -1058,6 +1071,34 @@ struct pfbhip_gridder {
         }
     }
 
+    // single-precision host arrays: uploaded as they are into a staging buffer, widened on the device
+    DevBuf<float> d_stage32;
+    void upload_f32(const float *host, size_t n, double *dst)
+    {
+        d_stage32.ensure(n);
+        PFB_HIP(hipMemcpyAsync(d_stage32.p, host, n * sizeof(float), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_widen_f32, dim3(uint32_t(ceil_div(int64_t(n), 256))), dim3(256), 0, stream, int64_t(n), d_stage32.p, dst);
+        PFB_HIP(hipGetLastError());
+        // (the staging buffer is reused by the next upload: in-order on this stream)
+    }
+    void download_f32(const double *src, size_t n, float *host)
+    {
+        d_stage32.ensure(n);
+        hipLaunchKernelGGL(k_narrow_f64, dim3(uint32_t(ceil_div(int64_t(n), 256))), dim3(256), 0, stream, int64_t(n), src, d_stage32.p);
+        PFB_HIP(hipGetLastError());
+        PFB_HIP(hipMemcpyAsync(host, d_stage32.p, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    }
+    void upload_vis_wgt_sp(const float *vis_host, const float *wgt_host)
+    {
+        if (vis_host) {
+            d_vis.ensure(size_t(nvis));
+            upload_f32(vis_host, size_t(nvis) * 2, reinterpret_cast<double *>(d_vis.p));
+        }
+        if (wgt_host) {
+            d_wgt.ensure(size_t(nvis));
+            upload_f32(wgt_host, size_t(nvis), d_wgt.p);
+        }
+    }
     void upload_vis_wgt(const double *vis_host, const double *wgt_host)
     {
         if (vis_host) {
@@ -2357,6 +2398,85 @@ int pfbhip_gridder_hessian(pfbhip_gridder *g, const double *x_host, const double
         }
         hessian_dev_impl(g, g->d_img.p, beam_host ? g->d_beam.p : nullptr, eta, wsum, g->d_img2.p);
         PFB_HIP(hipMemcpyAsync(out_host, g->d_img2.p, npix * sizeof(double), hipMemcpyDeviceToHost, st));
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+// ---- single-precision host arrays (precision = "single" of the reference's vis2im / im2vis, operators/gridder.py:58-100, with
+// double-precision accumulation: complex64 / float32 cross PCIe, every device buffer and sum stays double) ----
+int pfbhip_gridder_vis2dirty_sp(pfbhip_gridder *g, const float *vis_host, const float *wgt_host, float *dirty_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && dirty_host && (vis_host || g->nvis == 0), "NULL argument");
+        hipStream_t st = g->stream;
+        const int64_t npix = g->prm.nx * g->prm.ny;
+        g->upload_vis_wgt_sp(vis_host, wgt_host);
+        if (g->info.nactive)
+            hipLaunchKernelGGL(k_permute_in, blocks1d(g->info.nactive), dim3(256), 0, st, g->map, g->d_src.p,
+                               g->info.nactive, g->d_vis.p, wgt_host ? g->d_wgt.p : nullptr, int(g->shifting),
+                               g->info.lshift, g->info.mshift, g->info.nshift, g->d_sval.p);
+        PFB_HIP(hipGetLastError());
+        g->grid_and_finalize(g->d_sval.p, nullptr, 1.0, 0.0, nullptr, g->d_img.p);
+        g->download_f32(g->d_img.p, size_t(npix), dirty_host);
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int pfbhip_gridder_dirty2vis_sp(pfbhip_gridder *g, const float *dirty_host, const float *wgt_host, float *vis_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && dirty_host && (vis_host || g->nvis == 0), "NULL argument");
+        hipStream_t st = g->stream;
+        const int64_t npix = g->prm.nx * g->prm.ny;
+        g->upload_f32(dirty_host, size_t(npix), g->d_img.p);
+        g->upload_vis_wgt_sp(nullptr, wgt_host);
+        g->prepare_and_degrid(g->d_img.p, nullptr, g->d_sacc.p);
+        if (g->nvis) {
+            g->d_vis.ensure(size_t(g->nvis));
+            PFB_HIP(hipMemsetAsync(g->d_vis.p, 0, size_t(g->nvis) * sizeof(double2), st));
+            if (g->info.nactive)
+                hipLaunchKernelGGL(k_permute_out, blocks1d(g->info.nactive), dim3(256), 0, st, g->map, g->d_src.p,
+                                   g->info.nactive, g->d_sacc.p, wgt_host ? g->d_wgt.p : nullptr, int(g->shifting),
+                                   g->info.lshift, g->info.mshift, g->info.nshift, g->d_vis.p);
+            PFB_HIP(hipGetLastError());
+            g->download_f32(reinterpret_cast<const double *>(g->d_vis.p), size_t(g->nvis) * 2, vis_host);
+        }
+        PFB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int pfbhip_gridder_set_weights_sp(pfbhip_gridder *g, const float *wgt_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g, "NULL handle");
+        hipStream_t st = g->stream;
+        g->upload_vis_wgt_sp(nullptr, wgt_host);
+        g->d_swgt.ensure(size_t(std::max<int64_t>(g->info.nactive, 1)));
+        if (g->info.nactive)
+            hipLaunchKernelGGL(k_gather_f64, blocks1d(g->info.nactive), dim3(256), 0, st, g->d_src.p, g->info.nactive,
+                               wgt_host ? g->d_wgt.p : nullptr, g->d_swgt.p);
+        PFB_HIP(hipGetLastError());
+        PFB_HIP(hipStreamSynchronize(st));
+        g->weights_bound = true;
+    });
+}
+
+int pfbhip_gridder_hessian_sp(pfbhip_gridder *g, const float *x_host, const float *beam_host, double eta, double wsum,
+                              float *out_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && x_host && out_host, "NULL argument");
+        hipStream_t st = g->stream;
+        const size_t npix = size_t(g->prm.nx * g->prm.ny);
+        g->d_img.ensure(npix);
+        g->d_img2.ensure(npix);
+        g->upload_f32(x_host, npix, g->d_img.p);
+        if (beam_host) {
+            g->d_beam.ensure(npix);
+            g->upload_f32(beam_host, npix, g->d_beam.p);
+        }
+        hessian_dev_impl(g, g->d_img.p, beam_host ? g->d_beam.p : nullptr, eta, wsum, g->d_img2.p);
+        g->download_f32(g->d_img2.p, npix, out_host);
         PFB_HIP(hipStreamSynchronize(st));
     });
 }

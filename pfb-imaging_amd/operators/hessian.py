@@ -64,8 +64,9 @@ def hessian_slice(x, xout=None, uvw=None, weight=None, vis_mask=None, freq=None,
         # wsum / eta are folded into the device call (the last fused kernel writes beam * acc * corr / wsum + eta * x): the
         # reference's host passes `convim /= wsum`, `convim += eta * x` and the copy into xout each cost as much as the
         # whole device apply at 8192^2.  None keeps the reference's meaning: no normalisation / no Tikhonov term.
-        direct = xout is not None and xout.dtype == np.float64 and xout.flags.c_contiguous and xout.shape == x.shape \
-            and not np.shares_memory(xout, x)
+        # (a float32 x takes the single-precision boundary: float32 across PCIe, sums in double, float32 result)
+        direct = xout is not None and xout.dtype == x.dtype and x.dtype in (np.float32, np.float64) and xout.flags.c_contiguous \
+            and xout.shape == x.shape and not np.shares_memory(xout, x)
         # The device call folds in a POSITIVE wsum only (it reads wsum <= 0 as "no normalisation").  The reference divides by
         # whatever it is given (`if wsum is not None: convim /= wsum`, hessian.py:91-92): wsum = 0 there yields inf / nan, a
         # negative one flips the sign -- those cases keep the reference's host arithmetic.

@@ -88,8 +88,37 @@ class Gridder:
             raise ValueError(f"{name} shape {x.shape} != {(self.nx, self.ny)}")
         return x
 
+    # -- single precision at the boundary --------------------------------------
+    # complex64 visibilities / float32 images and weights (the reference's precision="single", operators/gridder.py:58-100) cross
+    # PCIe as they are -- half the bytes -- and are widened on the device; sums are formed in double (ducc0's
+    # double_precision_accumulation=True, the reference's default).  Results come back in single precision like ducc0's.
+    @staticmethod
+    def _is_sp(a, kind):
+        return isinstance(a, np.ndarray) and a.dtype == (np.complex64 if kind == "c" else np.float32)
+
+    def _sp_wgt(self, wgt):
+        if wgt is None:
+            return None
+        wgt = as_c(wgt, np.float32)
+        if wgt.shape != (self.nrow, self.nchan):
+            raise ValueError(f"wgt shape {wgt.shape} != {(self.nrow, self.nchan)}")
+        return wgt
+
+    def _sp_img(self, x, name):
+        x = as_c(x, np.float32)
+        if x.shape != (self.nx, self.ny):
+            raise ValueError(f"{name} shape {x.shape} != {(self.nx, self.ny)}")
+        return x
+
     # -- operators (host arrays) --------------------------------------------
     def vis2dirty(self, vis, wgt=None):
+        if self._is_sp(vis, "c") and (wgt is None or self._is_sp(wgt, "r")):
+            vis = as_c(vis, np.complex64)
+            if vis.shape != (self.nrow, self.nchan):
+                raise ValueError(f"vis shape {vis.shape} != {(self.nrow, self.nchan)}")
+            out = _lib.result_empty((self.nx, self.ny), np.float32)
+            check(lib().pfbhip_gridder_vis2dirty_sp(self._h, ptr(vis), ptr(self._sp_wgt(wgt)), ptr(out)))
+            return out
         vis, wgt = self._vis(vis), self._wgt(wgt)
         out = _lib.result_empty((self.nx, self.ny), np.float64)
         check(lib().pfbhip_gridder_vis2dirty(self._h, ptr(vis), ptr(wgt), ptr(out)))
@@ -101,19 +130,37 @@ class Gridder:
         check(lib().pfbhip_gridder_vis2dirty_dev(self._h, ptr(vis), ptr(wgt), out_dev.ptr))
 
     def dirty2vis(self, dirty, wgt=None):
+        if self._is_sp(dirty, "r") and (wgt is None or self._is_sp(wgt, "r")):
+            out = _lib.result_empty((self.nrow, self.nchan), np.complex64)
+            check(lib().pfbhip_gridder_dirty2vis_sp(self._h, ptr(self._sp_img(dirty, "dirty")), ptr(self._sp_wgt(wgt)), ptr(out)))
+            return out
         dirty, wgt = self._img(dirty), self._wgt(wgt)
         out = _lib.result_empty((self.nrow, self.nchan), np.complex128)
         check(lib().pfbhip_gridder_dirty2vis(self._h, ptr(dirty), ptr(wgt), ptr(out)))
         return out
 
     def set_weights(self, wgt):
+        if self._is_sp(wgt, "r"):
+            check(lib().pfbhip_gridder_set_weights_sp(self._h, ptr(self._sp_wgt(wgt))))
+            self._weights_token = object()
+            return
         wgt = self._wgt(wgt)
         check(lib().pfbhip_gridder_set_weights(self._h, ptr(wgt)))
         self._weights_token = object()
 
     def hessian(self, x, beam=None, eta=0.0, wsum=0.0, out=None):
         """beam * R^H W R (beam * x) / wsum + eta x with the weights bound by :meth:`set_weights`; ``out`` (C-contiguous
-        float64, not ``x``) receives the result in place."""
+        float64, not ``x``) receives the result in place.  A float32 ``x`` (with a float32 or no beam) takes the
+        single-precision boundary: float32 in, float32 out, sums in double."""
+        if self._is_sp(x, "r") and (beam is None or self._is_sp(beam, "r")):
+            x = self._sp_img(x, "x")
+            beam = None if beam is None else self._sp_img(beam, "beam")
+            if out is None:
+                out = _lib.result_empty(x.shape, np.float32)
+            elif out.shape != x.shape or out.dtype != np.float32 or not out.flags.c_contiguous or np.shares_memory(out, x):
+                raise ValueError("out must be a C-contiguous float32 array of the image shape that does not alias x")
+            check(lib().pfbhip_gridder_hessian_sp(self._h, ptr(x), ptr(beam), f64(eta or 0.0), f64(wsum or 0.0), ptr(out)))
+            return out
         x = self._img(x, "x")
         beam = None if beam is None else self._img(beam, "beam")
         if out is None:
@@ -249,10 +296,13 @@ def vis2dirty(*, uvw, freq, vis, wgt=None, mask=None, npix_x, npix_y, pixsize_x,
 
     ``nthreads``, ``double_precision_accumulation`` (the grid and image are always accumulated in
     double here), ``allow_nshift`` and ``gpu`` are accepted and ignored.  Output precision follows
-    ``vis`` (complex64 -> float32) like ducc0.
+    ``vis`` (complex64 -> float32) like ducc0; complex64 visibilities (and float32 weights) are uploaded as they
+    are and widened on the device (``pfbhip_gridder_vis2dirty_sp``).
     """
     vis_arr = np.asarray(vis)
     single = vis_arr.dtype == np.complex64
+    if single and wgt is not None and np.asarray(wgt).dtype != np.float32:
+        wgt = np.asarray(wgt, dtype=np.float32)  # (ducc0 wants the weights in the visibilities' precision)
     g, cached = _get_gridder(uvw, freq, mask, npix_x=int(npix_x), npix_y=int(npix_y), pixsize_x=float(pixsize_x),
                              pixsize_y=float(pixsize_y), center_x=float(center_x), center_y=float(center_y),
                              epsilon=float(epsilon), flip_u=bool(flip_u), flip_v=bool(flip_v), flip_w=bool(flip_w),
@@ -268,7 +318,7 @@ def vis2dirty(*, uvw, freq, vis, wgt=None, mask=None, npix_x, npix_y, pixsize_x,
             raise ValueError(f"dirty shape {dirty.shape} != {out.shape}")
         dirty[...] = out
         return dirty
-    return out.astype(np.float32) if single else out
+    return out.astype(np.float32, copy=False) if single else out
 
 
 def dirty2vis(*, uvw, freq, dirty, wgt=None, mask=None, pixsize_x, pixsize_y, center_x=0.0, center_y=0.0, epsilon,
@@ -279,6 +329,8 @@ def dirty2vis(*, uvw, freq, dirty, wgt=None, mask=None, pixsize_x, pixsize_y, ce
     if dirty_arr.ndim != 2:
         raise ValueError(f"dirty must be two-dimensional, got {dirty_arr.shape}")
     single = dirty_arr.dtype == np.float32
+    if single and wgt is not None and np.asarray(wgt).dtype != np.float32:
+        wgt = np.asarray(wgt, dtype=np.float32)
     nx, ny = dirty_arr.shape
     g, cached = _get_gridder(uvw, freq, mask, npix_x=int(nx), npix_y=int(ny), pixsize_x=float(pixsize_x),
                              pixsize_y=float(pixsize_y), center_x=float(center_x), center_y=float(center_y),
@@ -295,7 +347,7 @@ def dirty2vis(*, uvw, freq, dirty, wgt=None, mask=None, pixsize_x, pixsize_y, ce
             raise ValueError(f"vis shape {vis.shape} != {out.shape}")
         vis[...] = out
         return vis
-    return out.astype(np.complex64) if single else out
+    return out.astype(np.complex64, copy=False) if single else out
 
 
 # ducc0 exposes the same callables under ducc0.wgridder.experimental

@@ -240,3 +240,47 @@ def test_pcg_family_over_the_device_cg():
                     do_wgridding=True, epsilon=1e-7)
     assert rel(resid, dirty - plain(fields["MODEL_MOPPED"])) < 1e-10 and ds["RESIDUAL_MOPPED"] is fields["RESIDUAL_MOPPED"]
     clear_cache()
+
+
+def test_single_precision_boundary():
+    """precision = "single" end to end (round 4): complex64 visibilities, float32 weights / images cross PCIe as they are
+    (pfbhip_gridder_*_sp: widened on the device, sums in double = ducc0's double_precision_accumulation); results come back
+    in single precision and equal the double path on the float32-rounded inputs to float32 rounding of the result."""
+    from pfb_imaging_amd.operators.hessian import hessian_slice
+    from pfb_imaging_amd.wgridder import Gridder, dirty2vis, vis2dirty
+
+    c = case()
+    nx, ny = c["nx"], c["ny"]
+    kw = dict(npix_x=nx, npix_y=ny, pixsize_x=c["cell"], pixsize_y=c["cell"], center_x=0.0, center_y=0.0, epsilon=1e-6, flip_u=False,
+              flip_v=True, flip_w=False, do_wgridding=True, divide_by_n=False)
+    g = Gridder(c["uvw"], c["freq"], c["mask"], **kw)
+    v32, w32, x32 = c["vis"].astype(np.complex64), c["wgt"].astype(np.float32), c["x"].astype(np.float32)
+    d32 = g.vis2dirty(v32, w32)
+    assert d32.dtype == np.float32 and d32.shape == (nx, ny)
+    d64 = g.vis2dirty(v32.astype(np.complex128), w32.astype(np.float64))
+    assert d64.dtype == np.float64 and rel(d32, d64) < 2e-7            # one rounding of the result to float32
+    m32 = g.dirty2vis(x32, w32)
+    assert m32.dtype == np.complex64
+    assert rel(m32, g.dirty2vis(x32.astype(np.float64), w32.astype(np.float64))) < 2e-7
+    # mixed precisions keep the double path (what ducc0 would refuse; here: the wider type wins)
+    assert g.vis2dirty(v32, c["wgt"]).dtype == np.float64
+    g.set_weights(w32)
+    h32 = g.hessian(x32, eta=0.1, wsum=5.0)
+    assert h32.dtype == np.float32
+    g.set_weights(w32.astype(np.float64))
+    assert rel(h32, g.hessian(x32.astype(np.float64), eta=0.1, wsum=5.0)) < 2e-7
+    out = np.empty((nx, ny), np.float32)
+    assert g.hessian(x32, eta=0.1, wsum=5.0, out=out) is out and np.array_equal(out, h32)
+    with pytest.raises(ValueError):
+        g.hessian(x32, out=np.empty((nx, ny), np.float64))
+    g.close()
+    # the ducc0-signature callables and hessian_slice follow the input precision
+    sk = dict(uvw=c["uvw"], freq=c["freq"], mask=c["mask"], pixsize_x=c["cell"], pixsize_y=c["cell"], center_x=0.0, center_y=0.0,
+              epsilon=1e-6, flip_u=False, flip_v=True, flip_w=False, do_wgridding=True, divide_by_n=False)
+    assert vis2dirty(vis=v32, wgt=c["wgt"], npix_x=nx, npix_y=ny, **sk).dtype == np.float32
+    assert rel(vis2dirty(vis=v32, wgt=w32, npix_x=nx, npix_y=ny, **sk), d64) < 2e-7
+    assert dirty2vis(dirty=x32, **sk).dtype == np.complex64
+    xo = np.empty((nx, ny), np.float32)
+    hs = hessian_slice(x32, xout=xo, uvw=c["uvw"], weight=w32, vis_mask=c["mask"], freq=c["freq"], cell=c["cell"], epsilon=1e-6,
+                       eta=0.1, wsum=5.0)
+    assert hs is xo and rel(xo, h32) < 1e-6
