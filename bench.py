@@ -211,6 +211,11 @@ def host_path(case, g, wsum, reps=3):
     out["hessian_slice_readonly_inputs_ms"] = timed(lambda: hessian_slice(c["x"], **frozen))
     x_host = c["x"]
     out["handle_hessian_ms"] = timed(lambda: g.hessian(x_host, eta=1e-3, wsum=wsum))
+    # precision = "single" callers (float32 images and weights): half the PCIe bytes, sums still in double on the device
+    x32, w32 = c["x"].astype(np.float32), c["wgt"].astype(np.float32)
+    xout32 = np.empty_like(x32)
+    out["hessian_slice_float32_ms"] = timed(lambda: hessian_slice(x32, **dict(hkw, weight=w32)))
+    del x32, w32, xout32
     skw = dict(uvw=c["uvw"], freq=c["freq"], mask=c["mask"], pixsize_x=c["cell"], pixsize_y=c["cell"], center_x=0.0, center_y=0.0,
                epsilon=1e-7, flip_u=False, flip_v=True, flip_w=False, do_wgridding=True, divide_by_n=False, sigma_min=1.1,
                sigma_max=2.6)
