@@ -20,15 +20,18 @@ static int env_threads(const char *name, int dflt, int cap)
     const int v = std::atoi(e);
     return (v >= 256 && v <= cap && v % 64 == 0) ? v : dflt;  // (>= 256: the tile flush holds its cells in registers, sized for that)
 }
-int wd_scatter_threads()
+// Launches of fewer work items than three per CU (C1: ~300) cannot fill the chip with 256-thread workgroups: those take one
+// 768-thread workgroup per item.
+static int scatter_threads_for(uint32_t nwork)
 {
-    static const int t = env_threads("PFBHIP_WD_SCATTER_THREADS", 256, wd_threads());
-    return t;
+    static const int t = env_threads("PFBHIP_WD_SCATTER_THREADS", 0, wd_threads());
+    return t > 0 ? t : (nwork < 768u ? wd_threads() : 256);
 }
-static int wd_gather_threads_rt(int NJ)
+int wd_scatter_threads() { return wd_threads(); }  // (the largest: what the LDS limit is sized for)
+static int wd_gather_threads_rt(int NJ, uint32_t nwork)
 {
-    static const int t = env_threads("PFBHIP_WD_GATHER_THREADS", 256, MP_THREADS);
-    return std::min(t, wd_gather_threads(NJ));
+    static const int t = env_threads("PFBHIP_WD_GATHER_THREADS", 0, MP_THREADS);
+    return std::min(t > 0 ? t : (nwork < 768u ? 768 : 256), wd_gather_threads(NJ));
 }
 size_t wd_scatter_lds_bytes(int W)
 {
@@ -62,8 +65,9 @@ template <int W, int NJ>
 static void grid_wk(const GroupArgs &ga, const WdArgs &wa, const VisRec *rec, const double2 *pval, double2 *grid, hipStream_t st)
 {
     allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_wd<W, NJ>), 160 * 1024);
-    const size_t lds = wd_lds_doubles(W, wd_scatter_threads() / 64) * sizeof(double);
-    hipLaunchKernelGGL((k_grid_wd<W, NJ>), dim3(ga.a.nwork), dim3(wd_scatter_threads()), lds, st, ga, wa, rec, pval, grid);
+    const int threads = scatter_threads_for(ga.a.nwork);
+    const size_t lds = wd_lds_doubles(W, threads / 64) * sizeof(double);
+    hipLaunchKernelGGL((k_grid_wd<W, NJ>), dim3(ga.a.nwork), dim3(threads), lds, st, ga, wa, rec, pval, grid);
 }
 template <int W>
 static void grid_w(const GroupArgs &ga, const WdArgs &wa, const VisRec *rec, const double2 *pval, double2 *grid, hipStream_t st)
@@ -93,7 +97,7 @@ static void degrid_wk(const GroupArgs &ga, const WdArgs &wa, const VisRec *rec, 
                       const double *swgt, double2 *pval_out, hipStream_t st)
 {
     allow_dynamic_lds(reinterpret_cast<const void *>(&k_degrid_wd<W, NJ>), 160 * 1024);
-    hipLaunchKernelGGL((k_degrid_wd<W, NJ>), dim3(ga.a.nwork), dim3(wd_gather_threads_rt(NJ)), wd_gather_lds_bytes(), st, ga, wa, rec, grid, sacc,
+    hipLaunchKernelGGL((k_degrid_wd<W, NJ>), dim3(ga.a.nwork), dim3(wd_gather_threads_rt(NJ, ga.a.nwork)), wd_gather_lds_bytes(), st, ga, wa, rec, grid, sacc,
                        swgt, pval_out);
 }
 template <int W>
