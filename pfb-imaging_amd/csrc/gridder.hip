@@ -1299,7 +1299,10 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
     PFB_REQUIRE(best != nullptr || !(wgrid && prm.force_wmode == 2),  // (C-ABI encoding: 0 = plan decides, wmode + 1 otherwise)
                 "force_wmode=1: the polynomial w-plane scheme needs more than %d planes for this field of view and w range "
                 "(epsilon=%g); leave the scheme to the plan", MAX_POLY_PLANES, prm.epsilon);
-    PFB_REQUIRE(best != nullptr, "no ES kernel reaches epsilon=%g with sigma in [%g, %g] (double precision floor ~1e-12)",
+    // (the table's best row has a worst-position error of 2.3e-12; with the margins above the tightest epsilon a plan accepts is
+    // ~1.1e-11 with w-gridding, ~7e-12 without, and 1 / n_min times that with divide_by_n)
+    PFB_REQUIRE(best != nullptr, "no ES kernel reaches epsilon=%g with sigma in [%g, %g]: the tightest epsilon this kernel table admits "
+                "is ~1.1e-11 with w-gridding (~7e-12 without; times 1 / min(n) with divide_by_n) at sigma_max >= 2.5",
                 prm.epsilon, prm.sigma_min, prm.sigma_max);
     auto &info = g->info;
     info.W = best->W;

@@ -745,7 +745,7 @@ void fused_planes_fit(const FusedGeom &g, FusedPlanes &pl, bool residual)
             for (int d = 0; d < FUSED_SCMAX; ++d) {
                 long double tail = 0.0L;
                 for (int q = d + 1; q < M / 2; ++q) tail += fabsl(c[size_t(q)]);
-                // (1e-14 of a unit-modulus screen: five orders below the tightest epsilon a plan accepts; 2e-17 -- the
+                // (1e-14 of a unit-modulus screen: three orders below the tightest epsilon a plan accepts, ~1e-11; 2e-17 -- the
                 // rounding level -- cost C2 two to three more coefficients per chain)
                 if (tail <= 1e-14L) { deg = d; break; }
             }

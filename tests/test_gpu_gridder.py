@@ -569,6 +569,21 @@ def test_device_block_cache_reuse_and_flush():
     assert _lib.device_cache() == 0
 
 
+def test_poisoned_device_blocks():
+    """recycled device blocks are not zero.  One subprocess with PFBHIP_DEVCACHE_POISON=1 (every block filled with NaN
+    bytes before use) builds every kind of plan twice and compares (tests/_poison_worker.py)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PFBHIP_DEVCACHE_POISON="1")
+    env.pop("PFBHIP_SCATTER", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_poison_worker.py")], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and "poison ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_separable_screen_matches_general_form(monkeypatch):
     """The w-screen of a pass in separable form (per-plane column table x row factor x residual polynomials,
     csrc/rowfft_api.hpp FusedPlanes::sep) against the same plan with n - 1 and sincos per pixel (PFBHIP_SEPSCREEN=0),
