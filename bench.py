@@ -392,7 +392,11 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
         nstep[0] = 0
     comm.barrier()
     _lib.check(_lib.lib().pfbhip_synchronize())
-    g.profile(True)
+    # Stage timers (HIP events on the handle's stream) run inside the timed region -- except on small plans (C1), whose applies
+    # are replayed from a captured hipGraph unless a timer wants events between the kernels: those are timed clean and
+    # profiled in a second pass of the same steps.
+    two_pass = (not solve) and g.nactive < 2_000_000
+    g.profile(not two_pass)
     g.profile_get(reset=True)
     t0 = time.perf_counter()
     if solve:
@@ -403,6 +407,12 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
     _lib.check(_lib.lib().pfbhip_synchronize())
     comm.barrier()
     elapsed = time.perf_counter() - t0
+    if two_pass:
+        g.profile(True)
+        g.profile_get(reset=True)
+        for _ in range(args.steps):
+            step()
+        _lib.check(_lib.lib().pfbhip_synchronize())
     stages = g.profile_get(reset=True)
     g.profile(False)
     elapsed = comm.max_over_ranks(elapsed)

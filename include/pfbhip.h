@@ -143,6 +143,9 @@ typedef struct pfbhip_gridder_info {
      * functions per axis; phase centre on axis only).  Replaces the nderiv planes wmode 1 would use. */
     int32_t nderiv;
     double smax;
+    /* Hessian applies replayed from a captured hipGraph so far (opt-in: PFBHIP_GRAPH=1; measured at parity with eager
+     * launches even at C1's size, see gridder.hip) */
+    int64_t graph_replays;
 } pfbhip_gridder_info;
 
 int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw_host /* (nrow,3) */,

@@ -576,6 +576,22 @@ struct pfbhip_gridder {
     rocfft_plan fftB_fwd = nullptr, fftB_bwd = nullptr;  // ny rows of length nu
     rocfft_execution_info fft_info = nullptr;
     StageTimer timer;
+    // Captured Hessian applies, OPT-IN (PFBHIP_GRAPH=1).  Measured at C1 (round 4, gpurun_out/r04: 50 applies, no stage timers):
+    // eager 0.216 ms per apply for 0.211 ms of kernels, replayed 0.224 -- the host issues an apply's ~8 launches faster than
+    // the device runs them, and a dependent kernel boundary costs the same inside a graph.  (The "25 % of launch gaps" of
+    // round 3's C1 line were the stage timers' own events: 16 hipEventRecords per apply.)  Kept for hosts that cannot keep
+    // up (many bands per process).  Keyed by what a capture bakes in: the image pointers and the scalars; the device buffers the kernels read
+    // (weights, records, planes) keep their addresses for the life of the plan, so new weights or a new x need no new graph.
+    struct ApplyGraph {
+        const double *x, *beam;
+        double *out;
+        double eta, wsum;
+        int seen;              // calls with this key (the second one captures: the first has warmed every lazy set-up)
+        hipGraphExec_t exec;
+    };
+    std::vector<ApplyGraph> graphs;
+    int graph_mode = -1;       // -1 undecided, 0 off, 1 on (PFBHIP_GRAPH=1 on the hand-written FFT path)
+    int64_t graph_replays = 0;
     std::vector<double> wplanes;  // w of every plane (wavelengths)
     std::vector<double> nodes, lagr_coef;  // wmode 1: Chebyshev nodes and Lagrange denominators
 
@@ -588,6 +604,8 @@ struct pfbhip_gridder {
         if (fftB_fwd) rocfft_plan_destroy(fftB_fwd);
         if (fftB_bwd) rocfft_plan_destroy(fftB_bwd);
         if (fft_info) rocfft_execution_info_destroy(fft_info);
+        for (auto &ag : graphs)
+            if (ag.exec) (void)hipGraphExecDestroy(ag.exec);
         if (stream) (void)hipStreamDestroy(stream);
         if (clear_stream) (void)hipStreamDestroy(clear_stream);
         if (ev_clear) (void)hipEventDestroy(ev_clear);
@@ -2180,6 +2198,7 @@ int pfbhip_gridder_get_info(const pfbhip_gridder *g, pfbhip_gridder_info *info)
         std::swap(info->nu, info->nv);          // report the caller's orientation (the plan holds the transposed problem)
         std::swap(info->lshift, info->mshift);
         info->device_bytes = g->device_bytes();
+        info->graph_replays = g->graph_replays;
     });
 }
 
@@ -2327,8 +2346,68 @@ int pfbhip_gridder_set_weights(pfbhip_gridder *g, const double *wgt_host)
     });
 }
 
+static void hessian_dev_eager(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta, double wsum,
+                              double *out_dev);
+
+// The apply, replayed from a captured graph where that pays (see pfbhip_gridder::ApplyGraph).
 static void hessian_dev_impl(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta, double wsum,
                              double *out_dev)
+{
+    if (g->graph_mode < 0) {
+        const char *e = std::getenv("PFBHIP_GRAPH");
+        g->graph_mode = (e != nullptr && e[0] == '1' && g->fft_info == nullptr) ? 1 : 0;  // (rocFFT plans: not captured)
+    }
+    if (g->graph_mode == 0 || g->timer.enabled || g->stamp_mode != 0 || g->info.nwork == 0) {
+        hessian_dev_eager(g, x_dev, beam_dev, eta, wsum, out_dev);
+        return;
+    }
+    PFB_REQUIRE(g->weights_bound, "call pfbhip_gridder_set_weights before the Hessian");
+    pfbhip_gridder::ApplyGraph *slot = nullptr;
+    for (auto &ag : g->graphs)
+        if (ag.x == x_dev && ag.beam == beam_dev && ag.out == out_dev && ag.eta == eta && ag.wsum == wsum) slot = &ag;
+    if (slot == nullptr) {
+        if (g->graphs.size() >= 8) {  // (a caller cycling through many buffers: forget the oldest)
+            if (g->graphs.front().exec) (void)hipGraphExecDestroy(g->graphs.front().exec);
+            g->graphs.erase(g->graphs.begin());
+        }
+        g->graphs.push_back(pfbhip_gridder::ApplyGraph{x_dev, beam_dev, out_dev, eta, wsum, 0, nullptr});
+        slot = &g->graphs.back();
+    }
+    if (slot->exec != nullptr) {
+        PFB_HIP(hipGraphLaunch(slot->exec, g->stream));
+        ++g->graph_replays;
+        return;
+    }
+    if (slot->seen++ == 0) {  // first call with this key: eager (allocations, kernel attributes, plan-lazy state)
+        hessian_dev_eager(g, x_dev, beam_dev, eta, wsum, out_dev);
+        return;
+    }
+    hipGraph_t graph = nullptr;
+    PFB_HIP(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
+    try {
+        hessian_dev_eager(g, x_dev, beam_dev, eta, wsum, out_dev);
+    } catch (...) {
+        (void)hipStreamEndCapture(g->stream, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        g->graph_mode = 0;
+        throw;
+    }
+    hipError_t err = hipStreamEndCapture(g->stream, &graph);
+    if (err == hipSuccess && graph != nullptr) err = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (err != hipSuccess || slot->exec == nullptr) {  // capture not possible on this path: stay eager for good
+        (void)hipGetLastError();
+        slot->exec = nullptr;
+        g->graph_mode = 0;
+        hessian_dev_eager(g, x_dev, beam_dev, eta, wsum, out_dev);
+        return;
+    }
+    PFB_HIP(hipGraphLaunch(slot->exec, g->stream));  // (the capture itself ran nothing)
+    ++g->graph_replays;
+}
+
+static void hessian_dev_eager(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta, double wsum,
+                              double *out_dev)
 {
     PFB_REQUIRE(g->weights_bound, "call pfbhip_gridder_set_weights before the Hessian");
     hipStream_t st = g->stream;

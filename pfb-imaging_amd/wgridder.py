@@ -244,6 +244,13 @@ class Gridder:
                     wmin=i["wmin"], dw=i["dw"], nshift=i["nshift"], lshift=i["lshift"], mshift=i["mshift"],
                     tile=i["tile"], wmode=i["wmode"], wcenter=i["wcenter"], whalf=i["whalf"], nderiv=i["nderiv"])
 
+    def refresh_info(self):
+        """Re-read the plan's info (counters such as ``graph_replays`` change over its life)."""
+        info = GridderInfo()
+        check(lib().pfbhip_gridder_get_info(self._h, ct.byref(info)))
+        self.info = info.asdict()
+        return self.info
+
     def planes(self):
         w = np.empty(self.info["nplanes"], dtype=np.float64)
         check(lib().pfbhip_gridder_get_planes(self._h, ptr(w)))

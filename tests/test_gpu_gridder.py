@@ -792,3 +792,60 @@ def test_one_plane_w_scheme(K, widen, eps, npix, monkeypatch):
     g2, _, _ = gpu_plan(c, npix_x=nx, npix_y=ny, pixsize_x=cell, pixsize_y=cell * 1.1, epsilon=eps, center_x=1e-4)
     assert g2.info["wmode"] in (0, 1)
     g2.close()
+
+
+def test_apply_graph_replay(monkeypatch):
+    """PFBHIP_GRAPH=1: the Hessian apply replayed from a captured hipGraph (csrc/gridder.hip: hessian_dev_impl): the first call with
+    a set of buffers runs eagerly, the second captures, later ones replay -- with new contents of x, new weights, and in the
+    device CG loop; another output buffer or another eta gets a graph of its own; results equal the eager path (to the
+    summation order of the small plan's atomic tile flush)."""
+    from pfb_imaging_amd._lib import DeviceArray
+
+    c = make(nrow=4000, npix=64, widen=20.0, zscale=1e-3)
+    nx = c["nx"] = c["ny"] = 1100  # (the hand-written row FFT path: plans on rocFFT are not captured)
+    c["cell"] = c["cell"] * 64.0 / nx
+    c["x"] = np.random.default_rng(4).standard_normal((nx, nx))
+    monkeypatch.setenv("PFBHIP_GRAPH", "1")
+    g, kw, mask = gpu_plan(c)
+    g.set_weights(c["wgt"])
+    g.hessian(c["x"])  # (the mode is read at the first apply)
+    monkeypatch.setenv("PFBHIP_GRAPH", "0")
+    g0, _, _ = gpu_plan(c)
+    g0.set_weights(c["wgt"])
+    rng = np.random.default_rng(5)
+    xd, od, od2 = DeviceArray((nx, nx), np.float64), DeviceArray((nx, nx), np.float64), DeviceArray((nx, nx), np.float64)
+    rd = DeviceArray((nx, nx), np.float64)
+    for it in range(5):
+        x = rng.standard_normal((nx, nx))
+        xd.upload(x)
+        g.hessian_dev(xd, od, eta=0.2, wsum=3.0)
+        g0.hessian_dev(xd, rd, eta=0.2, wsum=3.0)
+        assert rel(od.download(), rd.download()) < 1e-10, it
+    assert g.refresh_info()["graph_replays"] == 4 and g0.refresh_info()["graph_replays"] == 0
+    # new weights: same graph, new result
+    w2 = c["wgt"] * (1.0 + rng.random(c["wgt"].shape))
+    g.set_weights(w2)
+    g0.set_weights(w2)
+    g.hessian_dev(xd, od, eta=0.2, wsum=3.0)
+    g0.hessian_dev(xd, rd, eta=0.2, wsum=3.0)
+    assert rel(od.download(), rd.download()) < 1e-10 and g.refresh_info()["graph_replays"] == 5
+    # another output buffer / another eta: their own graphs
+    for _ in range(3):
+        g.hessian_dev(xd, od2, eta=0.2, wsum=3.0)
+        g.hessian_dev(xd, od, eta=0.0, wsum=3.0)
+    g0.hessian_dev(xd, rd, eta=0.0, wsum=3.0)
+    assert rel(od.download(), rd.download()) < 1e-10
+    assert g.refresh_info()["graph_replays"] == 5 + 2 * 2
+    # the host-array entry and the device CG go through the same path
+    h = g.hessian(c["x"], eta=0.1, wsum=2.0)
+    h = g.hessian(c["x"], eta=0.1, wsum=2.0)
+    assert rel(h, g0.hessian(c["x"], eta=0.1, wsum=2.0)) < 1e-10
+    rhs = g0.hessian(c["x"], eta=0.5, wsum=2.0)
+    sol = g.cg(rhs, eta=0.5, wsum=2.0, tol=1e-10, maxit=50, minit=1)
+    sol0 = g0.cg(rhs, eta=0.5, wsum=2.0, tol=1e-10, maxit=50, minit=1)
+    assert g.last_cg["iters"] == g0.last_cg["iters"] and rel(sol, sol0) < 1e-5  # (50 iterations of an ill-conditioned solve: rounding order)
+    assert g.refresh_info()["graph_replays"] > 12
+    for d in (xd, od, od2, rd):
+        d.free()
+    g.close()
+    g0.close()
