@@ -17,8 +17,14 @@ al. 2019 for the exponential-of-semicircle kernel, the same form as
 
 ducc0 (locked 0.41.0) is not installable here, so the kernel (W, beta) table is
 this build's own (tools/make_kernel_table.py) and parity against ducc0's exact
-output is unpinned; parity is pinned against oracle.dft to the requested
+output is unpinned; parity is pinned against oracle.dft -- itself pinned to the
+reference's explicit_wdegridder / explicit_degridder -- to the requested
 epsilon (see oracle/__init__.py).
+
+Three w-schemes (GridParams.wmode), the restatement of the product's choice: 0 ES-kernel
+planes, 1 polynomial planes through Chebyshev nodes in w, 2 ONE plane with the rest of
+the w-term carried by differentiated gridding kernels (Plan._init_wd, pfb_oracle.c:
+pfbo_grid_plane_wd).
 
 The scatter/gather inner loops are C (oracle/pfb_oracle.c); FFTs are
 scipy.fft (pocketfft, the ancestor of ducc0.fft) with all host cores.
