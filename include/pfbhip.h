@@ -213,6 +213,9 @@ int pfbhip_gridder_debug_stamps(pfbhip_gridder *g, unsigned long long *out_host,
  * (nbatch, n0, n1) real / (nbatch, n0, n1/2+1) complex array
  * (src/pfb_imaging/operators/psf.py:20-32, operators/fft.py:10,39, operators/gridder.py:659,912). */
 int pfbhip_r2c_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1, double *out_host);
+/* r2c of ifftshift(x) over both axes, EVEN lengths only: fft2d / fft_cube of the reference (operators/fft.py:9-40, PSF -> PSFHAT);
+ * the shift is the checkerboard sign (-1)^(k0 + k1) on the spectrum, applied on the device. */
+int pfbhip_r2c_2d_centred(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1, double *out_host);
 int pfbhip_c2r_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1 /* lastsize */, double *out_host);
 
 /* Hand-written batched row FFT (the second-axis pass of the plane transform), exposed for tests and
@@ -246,6 +249,11 @@ int pfbhip_psfconv_apply(pfbhip_psfconv *p, const double *x_host, int64_t psf_sl
                          double shift, double scale, double eta, int accumulate, double *out_host);
 int pfbhip_psfconv_apply_dev(pfbhip_psfconv *p, const double *x_dev, int64_t psf_slot, int64_t beam_slot, int mode,
                              double shift, double scale, double eta, int accumulate, double *out_dev);
+/* HessPSF.idot's direct estimate (operators/hessian.py:369-400): mode 2 with the taper in taper_slot, then -- beam_slot >= 0 --
+ * x /= beam^2 where x > 0 and beam > min_beam, on the device (the reference divides on the host).  raw_host (may be NULL)
+ * receives the estimate before the beam division, out_host after it. */
+int pfbhip_psfconv_direct(pfbhip_psfconv *p, const double *x_host, int64_t psf_slot, int64_t taper_slot, double shift,
+                          int64_t beam_slot, double min_beam, double *raw_host, double *out_host);
 
 /* Single-precision host arrays: the reference's precision="single" (vis2im / im2vis, operators/gridder.py:58-100:
  * complex64 visibilities, float32 weights and images) with double-precision accumulation (ducc0's

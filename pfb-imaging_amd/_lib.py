@@ -77,13 +77,13 @@ SYMBOLS = (
     "pfbhip_gridder_degrid_dev", "pfbhip_gridder_grid_dev", "pfbhip_gridder_profile", "pfbhip_gridder_profile_get",
     "pfbhip_gridder_debug_stamps",
     "pfbhip_gridder_cg", "pfbhip_gridder_cg_dev",
-    "pfbhip_r2c_2d", "pfbhip_c2r_2d", "pfbhip_debug_rowfft",
+    "pfbhip_r2c_2d", "pfbhip_r2c_2d_centred", "pfbhip_c2r_2d", "pfbhip_debug_rowfft",
     "pfbhip_psi_create", "pfbhip_psi_destroy", "pfbhip_psi_shape", "pfbhip_psi_dot", "pfbhip_psi_hdot",
     "pfbhip_psi_dot_dev", "pfbhip_psi_hdot_dev", "pfbhip_dual_update", "pfbhip_l21_vtilde_sum_dev",
     "pfbhip_l21_scale_dev", "pfbhip_prox_21m", "pfbhip_positivity", "pfbhip_positivity_dev", "pfbhip_primal_dual",
     "pfbhip_psfconv_power_method", "pfbhip_gridder_power_method",
     "pfbhip_psfconv_create", "pfbhip_psfconv_destroy", "pfbhip_psfconv_set_psfhat", "pfbhip_psfconv_set_beam",
-    "pfbhip_psfconv_apply", "pfbhip_psfconv_apply_dev", "pfbhip_psfconv_cg",
+    "pfbhip_psfconv_apply", "pfbhip_psfconv_apply_dev", "pfbhip_psfconv_direct", "pfbhip_psfconv_cg",
     "pfbhip_uvcell_index", "pfbhip_compute_counts", "pfbhip_counts_divide", "pfbhip_box_sum_counts",
     "pfbhip_filter_extreme_counts", "pfbhip_imaging_weights",
     "pfbhip_comm_unique_id", "pfbhip_comm_create", "pfbhip_comm_destroy", "pfbhip_comm_reduce_sum",

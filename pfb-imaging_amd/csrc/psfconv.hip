@@ -328,6 +328,41 @@ int pfbhip_psfconv_apply(pfbhip_psfconv *p, const double *x_host, int64_t psf_sl
     });
 }
 
+// HessPSF.idot's direct estimate (operators/hessian.py:369-387 of the reference): out = taper-weighted division by (psfhat + shift)
+// (mode 2 with the taper as the image-plane multiplier), then -- where a beam is bound -- the beam division the reference does on
+// the host, x /= beam^2 where x > 0 and beam > min_beam, on the device.  raw_host (may be NULL) receives the estimate BEFORE the
+// division (the CG start vector), out_host the divided one.
+__global__ void k_beam_divide(int64_t n, const double *__restrict__ beam, double min_beam, double *__restrict__ x)
+{
+    const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i], b = beam[i];
+    if (v > 0.0 && b > min_beam) x[i] = v / (b * b);
+}
+
+int pfbhip_psfconv_direct(pfbhip_psfconv *p, const double *x_host, int64_t psf_slot, int64_t taper_slot, double shift,
+                          int64_t beam_slot, double min_beam, double *raw_host, double *out_host)
+{
+    return guarded([&] {
+        PFB_REQUIRE(p && x_host && out_host, "NULL argument");
+        const size_t n = size_t(p->nx) * size_t(p->ny);
+        p->d_x.ensure(n);
+        p->d_out.ensure(n);
+        PFB_HIP(hipMemcpyAsync(p->d_x.p, x_host, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+        p->apply(p->d_x.p, psf_slot, taper_slot, 2, shift, 1.0, 0.0, 0, p->d_out.p);
+        if (raw_host) PFB_HIP(hipMemcpyAsync(raw_host, p->d_out.p, n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        if (beam_slot >= 0) {
+            PFB_REQUIRE(beam_slot < int64_t(p->beam.size()) && p->beam[size_t(beam_slot)]->bound, "beam slot %lld is not bound",
+                        (long long)beam_slot);
+            hipLaunchKernelGGL(k_beam_divide, dim3(uint32_t(ceil_div(int64_t(n), 256))), dim3(256), 0, p->stream, int64_t(n),
+                               p->beam[size_t(beam_slot)]->data.p, min_beam, p->d_out.p);
+            PFB_HIP(hipGetLastError());
+        }
+        PFB_HIP(hipMemcpyAsync(out_host, p->d_out.p, n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        PFB_HIP(hipStreamSynchronize(p->stream));
+    });
+}
+
 int pfbhip_psfconv_cg(pfbhip_psfconv *p, int64_t nparts, const int64_t *psf_slots, const int64_t *beam_slots,
                       double scale, double eta, const double *rhs_host, double *x_host, int has_x0, double tol,
                       int maxit, int minit, pfbhip_cg_info *info)
@@ -354,10 +389,33 @@ int pfbhip_psfconv_cg(pfbhip_psfconv *p, int64_t nparts, const int64_t *psf_slot
 
 // ---- stand-alone r2c / c2r (host arrays) ------------------------------------------------
 
+// out[k0][k1] *= (-1)^(k0 + k1): the spectrum of ifftshift(x) from the spectrum of x when both lengths are even
+__global__ void k_checker_sign(double2 *a, int64_t n0, int64_t nh)
+{
+    const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i >= n0 * nh) return;
+    const int64_t k0 = i / nh, k1 = i - k0 * nh;
+    if ((k0 + k1) & 1) a[i] = make_double2(-a[i].x, -a[i].y);
+}
+
+static int r2c_2d_impl(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1, double *out_host, bool centred);
+
 int pfbhip_r2c_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1, double *out_host)
+{
+    return r2c_2d_impl(in_host, nbatch, n0, n1, out_host, false);
+}
+
+int pfbhip_r2c_2d_centred(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1, double *out_host)
+{
+    return r2c_2d_impl(in_host, nbatch, n0, n1, out_host, true);
+}
+
+static int r2c_2d_impl(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1, double *out_host, bool centred)
 {
     return guarded([&] {
         PFB_REQUIRE(in_host && out_host && nbatch >= 0 && n0 >= 1 && n1 >= 1, "bad r2c arguments");
+        PFB_REQUIRE(!centred || (n0 % 2 == 0 && n1 % 2 == 0), "the centred transform needs even lengths (%lld, %lld)", (long long)n0,
+                    (long long)n1);
         hipStream_t st;
         PFB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         struct Guard {
@@ -372,6 +430,10 @@ int pfbhip_r2c_2d(const double *in_host, int64_t nbatch, int64_t n0, int64_t n1,
         for (int64_t b = 0; b < nbatch; ++b) {
             PFB_HIP(hipMemcpyAsync(d_in.p, in_host + size_t(b) * nr, nr * sizeof(double), hipMemcpyHostToDevice, st));
             fft.r2c(d_in.p, d_out.p);
+            if (centred) {
+                hipLaunchKernelGGL(k_checker_sign, dim3(uint32_t(ceil_div(int64_t(nc), 256))), dim3(256), 0, st, d_out.p, n0, n1 / 2 + 1);
+                PFB_HIP(hipGetLastError());
+            }
             PFB_HIP(hipMemcpyAsync(out_host + size_t(b) * nc * 2, d_out.p, nc * sizeof(double2), hipMemcpyDeviceToHost,
                                    st));
         }

@@ -26,7 +26,9 @@ def _last_two(a, axes):
         raise NotImplementedError(f"only transforms over the last two axes are supported (axes={axes}, ndim={nd})")
 
 
-def r2c(a, axes=(-2, -1), forward=True, inorm=0, out=None, nthreads=1):
+def r2c(a, axes=(-2, -1), forward=True, inorm=0, out=None, nthreads=1, centred=False):
+    """``centred=True`` (not a ducc0 keyword; used by ``operators.fft``): the transform of ``ifftshift(a)`` over both axes for
+    even lengths, the shift applied to the spectrum on the device."""
     if not forward or inorm != 0:
         raise NotImplementedError("r2c supports forward=True, inorm=0 (the reference's only use)")
     _lib.require_gpu()
@@ -35,7 +37,8 @@ def r2c(a, axes=(-2, -1), forward=True, inorm=0, out=None, nthreads=1):
     n0, n1 = a.shape[-2:]
     nbatch = int(np.prod(a.shape[:-2], dtype=np.int64))
     res = np.empty(a.shape[:-2] + (n0, n1 // 2 + 1), dtype=np.complex128)
-    check(lib().pfbhip_r2c_2d(ptr(a), i64(nbatch), i64(n0), i64(n1), ptr(res)))
+    fn = lib().pfbhip_r2c_2d_centred if centred else lib().pfbhip_r2c_2d
+    check(fn(ptr(a), i64(nbatch), i64(n0), i64(n1), ptr(res)))
     if out is not None:
         out[...] = res
         return out

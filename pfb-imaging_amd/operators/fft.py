@@ -11,11 +11,15 @@ import numpy as np
 from .. import fft as _fft
 
 
-def _shifted(x):
+def _r2c_centred(x, axes):
+    """``r2c(ifftshift(x))``: for even lengths (every PSF size the reference produces, utils/misc.py:917-951) the shift is a
+    checkerboard sign on the spectrum, applied on the device; odd lengths shift on the host."""
     x = np.asarray(x)
     if x.dtype not in (np.float32, np.float64):
         x = x.astype(np.float64)
-    return np.fft.ifftshift(x, axes=(-2, -1))
+    if x.shape[-2] % 2 == 0 and x.shape[-1] % 2 == 0:
+        return _fft.r2c(x, axes=axes, forward=True, inorm=0, centred=True)
+    return _fft.r2c(np.fft.ifftshift(x, axes=(-2, -1)), axes=axes, forward=True, inorm=0)
 
 
 def fft2d(x, nthreads=1):
@@ -24,7 +28,7 @@ def fft2d(x, nthreads=1):
     x = np.asarray(x)
     if x.ndim != 2:
         raise ValueError(f"fft2d expects a 2-D image, got shape {x.shape}")
-    out = _fft.r2c(_shifted(x), axes=(0, 1), forward=True, inorm=0)
+    out = _r2c_centred(x, (0, 1))
     return out.astype(np.complex64) if x.dtype == np.float32 else out
 
 
@@ -33,5 +37,5 @@ def fft_cube(x, nthreads=1):
     x = np.asarray(x)
     if x.ndim != 3:
         raise ValueError(f"fft_cube expects a (nband, nx, ny) cube, got shape {x.shape}")
-    out = _fft.r2c(_shifted(x), axes=(1, 2), forward=True, inorm=0)
+    out = _r2c_centred(x, (1, 2))
     return out.astype(np.complex64) if x.dtype == np.float32 else out

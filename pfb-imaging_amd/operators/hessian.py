@@ -207,9 +207,12 @@ class HessPSF(object):
     def hdot(self, x):
         return self.dot(x)
 
-    def _direct(self, xb, b):
-        self._plan.apply(xb, b, beam_slot=self._taper_slot, mode=2, shift=float(self.eta[b] * np.sqrt(self.nx * self.ny)),
-                         out=self.xout[b])
+    def _direct_beam(self, xb, b, raw=None):
+        """The direct estimate with the reference's beam division (hessian.py:381-386, 395-399: ``xout /= beam**2`` where
+        ``xout > 0`` and ``beam > min_beam``) done on the device; ``raw`` receives the estimate before the division."""
+        shift = float(self.eta[b] * np.sqrt(self.nx * self.ny))
+        bslot = -1 if self.beam[b] is None else b
+        self._plan.direct(xb, b, self._taper_slot, shift, beam_slot=bslot, min_beam=float(self.min_beam), out=self.xout[b], raw=raw)
         return self.xout[b]
 
     def idot(self, x, mode="psf", x0=None, init_x0=True):
@@ -219,19 +222,13 @@ class HessPSF(object):
             # beam division lands in self.xout after x0[b] has taken its copy.
             x0 = np.zeros_like(xtmp)
             for b in range(self.nband):
-                x0[b] = self._direct(xtmp[b], b)
-                if self.beam[b] is not None:
-                    mask = (self.xout[b] > 0) & (self.beam[b] > self.min_beam)
-                    self.xout[b, mask] /= self.beam[b, mask] ** 2
+                self._direct_beam(xtmp[b], b, raw=x0[b])
         else:
             x0 = np.zeros_like(xtmp)
 
         if mode == "direct":
             for b in range(self.nband):
-                self._direct(xtmp[b], b)
-                if self.beam[b] is not None:
-                    mask = (self.xout[b] > 0) & (self.beam[b] > self.min_beam)
-                    self.xout[b, mask] /= self.beam[b, mask] ** 2
+                self._direct_beam(xtmp[b], b)
         elif mode == "psf":
             for b in range(self.nband):
                 bslot = -1 if self.beam[b] is None else b

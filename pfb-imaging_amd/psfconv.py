@@ -65,6 +65,17 @@ class PsfConv:
             out[...] = target
         return out
 
+    def direct(self, x, psf_slot, taper_slot, shift, beam_slot=-1, min_beam=0.0, out=None, raw=None):
+        """``hess_direct`` backward (division by ``psfhat + shift`` under the taper) followed, where ``beam_slot >= 0``, by the beam
+        division of ``HessPSF.idot`` -- ``x /= beam**2`` where ``x > 0`` and ``beam > min_beam`` -- on the device.  ``raw`` (optional)
+        receives the estimate before the division, ``out`` after it."""
+        x = as_c(x, np.float64)
+        out = np.empty_like(x) if out is None else out
+        assert out.flags.c_contiguous and out.dtype == np.float64 and (raw is None or (raw.flags.c_contiguous and raw.dtype == np.float64))
+        check(lib().pfbhip_psfconv_direct(self._h, ptr(x), i64(psf_slot), i64(taper_slot), f64(shift), i64(beam_slot), f64(min_beam),
+                                          ptr(raw), ptr(out)))
+        return out
+
     def cg(self, rhs, psf_slots, beam_slots, scale=1.0, eta=0.0, x0=None, tol=1e-5, maxit=500, minit=100):
         rhs = as_c(rhs, np.float64)
         x = np.zeros_like(rhs) if x0 is None else np.array(x0, dtype=np.float64, order="C")

@@ -103,6 +103,9 @@ def test_fft2d_fft_cube_match_numpy():
     assert fft2d(psf[1].astype(np.float32)).dtype == np.complex64
     with pytest.raises(ValueError):
         fft2d(psf)
+    # odd lengths: the shift is not a sign pattern on the spectrum (host ifftshift in front of the transform)
+    odd = rng.standard_normal((2, 45, 38))
+    assert rel(fft_cube(odd), np.fft.rfft2(np.fft.ifftshift(odd, axes=(1, 2)), axes=(1, 2))) < 1e-13
 
 
 def test_imaging_weight_chain_equals_the_steps():

@@ -111,6 +111,14 @@ def test_hesspsf_dot_idot():
     assert rel(sol, x) < 1e-6
     d = h.idot(rhs, mode="direct")
     assert d.shape == x.shape and np.isfinite(d).all()
+    # the beam division of the direct estimate (hessian.py:381-386, 395-399; on the device since round 4) == the reference's host
+    # statement applied to the estimate of the same operator without a beam
+    hn = HessPSF(32, 32, abspsf, beam=None, eta=eta)
+    dn = hn.idot(rhs, mode="direct")
+    want = dn.copy()
+    msk = (want > 0) & (beam > h.min_beam)
+    want[msk] /= beam[msk] ** 2
+    assert msk.any() and (~msk).any() and rel(d, want) < 1e-13
     with pytest.raises(ValueError):
         h.idot(rhs, mode="nonsense")
     with pytest.raises(ValueError):
