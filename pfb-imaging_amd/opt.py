@@ -614,6 +614,42 @@ class PCG:
                          verbosity=self.verbosity, report_freq=self.report_freq)
 
 
+def pcg_psf(psfhat, b, x0, beam, lastsize, nthreads, eta, cgopts, compute=True):
+    """Per-band CG on the PSF-approximate Hessian ``beam (PSF (*) (beam x)) + eta x`` (opt/pcg.py:317-441).  The reference wraps one
+    ``pcg`` over ``hessian_psf_slice`` per band in a dask ``blockwise`` graph (its ``x / eta`` preconditioner is a scalar and leaves
+    the CG iterates unchanged); here every band's solve runs on the device (``pfbhip_psfconv_cg``) and the model cube comes back
+    as a numpy array (``compute`` is accepted; there is no graph to defer).  ``cgopts``: ``tol, maxit, minit`` (+ the reporting keys,
+    ignored)."""
+    from .psfconv import cached_plan, cached_psf_slot
+
+    psfhat, b = np.asarray(psfhat), np.asarray(b)
+    if b.ndim != 3 or psfhat.ndim != 3 or psfhat.shape[0] != b.shape[0]:
+        raise ValueError(f"psfhat {psfhat.shape} / b {b.shape}: expected (nband, nx_psf, nyo2) and (nband, nx, ny)")
+    nband, nx, ny = b.shape
+    eta = np.tile(eta, nband) if isinstance(eta, float) else np.array(eta)
+    assert eta.size == nband
+    if beam is not None:
+        beam = np.asarray(beam)
+        if beam.ndim == 2:
+            beam = beam[None]
+        if beam.shape[0] == 1:
+            beam = np.tile(beam, (nband, 1, 1))
+        elif beam.shape[0] != nband:
+            raise ValueError("Beam has incorrect shape")
+    x0 = np.zeros_like(b) if x0 is None else np.asarray(x0)
+    opts = {k: v for k, v in dict(cgopts or {}).items() if k in ("tol", "maxit", "minit")}
+    plan = cached_plan(nx, ny, psfhat.shape[1], int(lastsize))
+    model = np.zeros((nband, nx, ny), dtype=b.dtype)
+    for k in range(nband):
+        slot = cached_psf_slot(plan, np.abs(psfhat[k]))
+        bslot = -1
+        if beam is not None:
+            bslot = 8 + k % 8   # (beam slots of the shared plan: a small ring, rebound per band)
+            plan.set_beam(bslot, beam[k])
+        model[k] = plan.cg(b[k], [slot], [bslot], scale=1.0, eta=float(eta[k]), x0=x0[k], **opts)
+    return model
+
+
 def _ds_get(ds, name):
     """Field ``name`` of an xarray-like dataset or a plain mapping, as a numpy array (None if absent)."""
     if isinstance(ds, dict):

@@ -39,8 +39,18 @@ def test_r2c_c2r_good_size():
     out = np.empty_like(ah)
     assert r2c(a, axes=(-2, -1), out=out) is out
     assert good_size(11468) == 11520 and good_size(127) == 128 and good_size(1000, True) == 1000
+    # the other forms ducc0 offers for two-axis transforms: any pair of axes, both signs, inorm 0 / 1 / 2
+    ref01 = np.fft.rfftn(a, axes=(2, 0))                      # transform over axes (2, 0): axis 0 becomes half-complex
+    got01 = r2c(a, axes=(2, 0), forward=True, inorm=0)
+    assert got01.shape == ref01.shape == (2, 36, 50) and rel(got01, ref01) < 1e-13
+    assert rel(r2c(a, axes=(1, 2), forward=False, inorm=1), np.conj(np.fft.rfft2(a, axes=(1, 2))) / np.sqrt(36 * 50)) < 1e-13
+    assert rel(c2r(got01, axes=(2, 0), forward=False, lastsize=3, inorm=2), a) < 1e-13
+    assert rel(c2r(np.conj(ah), axes=(1, 2), forward=True, lastsize=50, inorm=0), a * (36 * 50)) < 1e-13
+    assert rel(c2r(ah, axes=(1, 2), forward=False, lastsize=50, inorm=1), a * np.sqrt(36 * 50)) < 1e-13
     with pytest.raises(NotImplementedError):
-        r2c(a, axes=(0, 1))
+        r2c(a, axes=(0,))
+    with pytest.raises(ValueError):
+        r2c(a, axes=(1, 2), inorm=3)
 
 
 def test_psf_convolve_slice_cube_fscube():
@@ -123,6 +133,23 @@ def test_hesspsf_dot_idot():
         h.idot(rhs, mode="nonsense")
     with pytest.raises(ValueError):
         h.dot(np.zeros((1, 2, 32, 32)))
+
+
+def test_pcg_psf_per_band_solves():
+    """opt.pcg_psf (opt/pcg.py:317-441): per-band CG on beam (PSF (*) (beam x)) + eta x == the numpy restatement's solve."""
+    from pfb_imaging_amd.opt import pcg_psf
+
+    psf, psfhat, abspsf, x, beam = _psf_case(nband=2, nx=32, ny=32, nxp=64, nyp=64, seed=5)
+    psfhat = 1.0 + 0.2 * psfhat / np.abs(psfhat).max()      # complex: pcg_psf takes the magnitude itself
+    eta = np.array([0.1, 0.3])
+    rhs = fftconv.hess_psf_dot(x, np.abs(psfhat), 64, beam=beam, eta=eta)
+    sol = pcg_psf(psfhat, rhs, np.zeros_like(rhs), beam, 64, 1, eta, dict(tol=1e-11, maxit=400, minit=1, verbosity=0))
+    assert sol.shape == x.shape and rel(sol, x) < 1e-7
+    one = pcg_psf(psfhat, rhs, None, beam[0], 64, 1, 0.2, dict(tol=1e-9, maxit=300, minit=1), compute=False)   # 2-D beam, float eta
+    ref = fftconv.hess_psf_dot(one, np.abs(psfhat), 64, beam=np.tile(beam[:1], (2, 1, 1)), eta=np.array([0.2, 0.2]))
+    assert rel(ref, rhs) < 1e-6
+    with pytest.raises(ValueError):
+        pcg_psf(psfhat, rhs, None, beam[:, :16], 64, 1, eta, {})
 
 
 def _tree_parts(nx, ny, nxp, nyp, nparts, ncorr, seed, delta=False):
