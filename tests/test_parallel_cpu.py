@@ -78,3 +78,18 @@ def test_two_rank_socket_bootstrap():
     for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, so[-2000:] + se[-4000:]
         assert f"rank {rank} ok" in so
+
+
+def test_two_rank_socket_under_the_launcher():
+    """The way the driver starts bench.py for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P ...` -- the launcher's own store owns MASTER_PORT; the product's rendezvous must come up beside it
+    from the environment the launcher sets (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT), without importing torch."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1", PFBHIP_RDZV_TIMEOUT="120")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_gloo_worker.py"), "socket"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "rank 0 ok" in p.stdout and "rank 1 ok" in p.stdout
