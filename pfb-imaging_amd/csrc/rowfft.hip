@@ -647,6 +647,131 @@ __global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft(const
     else planes_loop(std::false_type{});
 }
 
+// Single-plane launches, PERSISTENT form (round 4: the one-plane w-scheme).  Knock-outs on k_fused_pad_fft
+// at C2 with one plane (0.93 ms): without the pre-pass loads 0.69, without the stores 0.70, the transform alone 0.49 -- one
+// workgroup per CU serialises its load phase (128 KB per row at the ~10 B per clock one CU pulls), its passes and its store
+// phase.  Here a workgroup walks its rows; the NEXT row's x, corr [, beam] are requested in S::NP batches at the hook points of
+// the transform (rowfft.hpp: RfNoHook) and banked into the LDS image row -- thread-private cells the first pass of THIS row has
+// already read -- one pass later, so the requests fly under the passes; the row's scattered stores are issued last and drain
+// under the next row's passes.
+template <class S, bool BEAM>
+struct PadPrefetch {
+    static constexpr int NB = S::NP;                              // batches = hook points - 1
+    static constexpr int BS = (S::NSLOT + NB - 1) / NB;           // slots per batch
+    const FusedGeom &g;
+    const double *xr, *cr, *br;  // the image row after the one being transformed
+    double *lrow;
+    int t;
+    double vx[BS], vc[BS], vb[BEAM ? BS : 1];
+    template <int B>
+    __device__ __forceinline__ void issue(const double *x, const double *c, const double *bm)
+    {
+        rf_for_each_load<S>(t, [&](int u, int slot) {
+            if (slot / BS == B) {
+                const int ixc = max(fg_ix(g, u), 0);
+                vx[slot % BS] = x[ixc];
+                vc[slot % BS] = c[ixc];
+                if constexpr (BEAM) vb[slot % BS] = bm[ixc];
+            }
+        });
+    }
+    template <int B>
+    __device__ __forceinline__ void bank()
+    {
+        rf_for_each_load<S>(t, [&](int u, int slot) {
+            if (slot / BS == B) {
+                const int ix = fg_ix(g, u);
+                double v = vx[slot % BS] * vc[slot % BS];  // (x * corr) * beam: the rounding order of k_prepare_img
+                if constexpr (BEAM) v *= vb[slot % BS];
+                if (ix >= 0) lrow[ix] = v;
+            }
+        });
+    }
+    // point P: bank batch P - 1 (requested one pass earlier), request batch P.  (Requesting the first batch in front of the
+    // previous row's stores instead, so that it does not queue behind them, was measured and is slower: 0.97 vs 0.78 ms.)
+    template <int P>
+    __device__ __forceinline__ void at()
+    {
+        if constexpr (P >= 1 && P <= NB) bank<P - 1>();
+        if constexpr (P < NB) issue<P>(xr, cr, br);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+template <class S, bool SC, bool BEAM>
+__global__ void __launch_bounds__(S::T, S::WAVES_PER_SIMD) k_fused_pad_fft_p(const double2 *tw, FusedGeom g, const uint8_t *occ,
+                                                           FusedPrep prep, FusedPlanes planes, int do_w, double2 *B)
+{
+    extern __shared__ double rf_lds[];
+    double *lrow = rf_lds + S::LDS_BYTES / sizeof(double);
+    auto row_of = [&](int blk) {  // (the XCD grouping of the transposed stores: see k_fused_pad_fft; gridDim.x is a multiple of 64)
+        if (g.tpitch > 0 && blk < (g.ny & ~63)) {
+            const int r = blk & 63;
+            return (blk & ~63) + (r & 7) * 8 + (r >> 3);
+        }
+        return blk;
+    };
+    uint32_t omask = 0;
+#pragma unroll
+    for (int e = 0; e < S::E; ++e) omask |= (occ[S::out_pos(int(threadIdx.x), e) >> 5] ? 1u : 0u) << e;
+    double cc[FUSED_SCMAX], ss[FUSED_SCMAX];
+#pragma unroll
+    for (int q = 0; q < FUSED_SCMAX; ++q) {
+        cc[q] = SC ? planes.cs[0][q] : 0.0;
+        ss[q] = SC ? planes.sn[0][q] : 0.0;
+    }
+    int blk = blockIdx.x;
+    if (blk >= g.ny) return;
+    const int G = int(gridDim.x);
+    auto rowptr = [&](const double *base, int bk) {  // row of block bk (past the end: this workgroup's first row again, read and dropped)
+        const int yy = row_of(bk < g.ny ? bk : int(blockIdx.x));
+        return base + size_t(yy) * size_t(g.nx);
+    };
+    const double *bsrc = BEAM ? prep.beam : prep.corr;
+    PadPrefetch<S, BEAM> hook{g, nullptr, nullptr, nullptr, lrow, int(threadIdx.x), {}, {}, {}};
+    {   // the first row's image values: every batch in turn (pre-pass)
+        const double *x0 = rowptr(prep.x, blk), *c0 = rowptr(prep.corr, blk), *b0 = rowptr(bsrc, blk);
+        hook.template issue<0>(x0, c0, b0);
+        hook.template bank<0>();
+        if constexpr (S::NP > 1) {
+            hook.template issue<1>(x0, c0, b0);
+            hook.template bank<1>();
+        }
+        if constexpr (S::NP > 2) {
+            hook.template issue<2>(x0, c0, b0);
+            hook.template bank<2>();
+        }
+        if constexpr (S::NP > 3) {
+            hook.template issue<3>(x0, c0, b0);
+            hook.template bank<3>();
+        }
+        static_assert(S::NP <= 4, "PadPrefetch: at most four batches");
+    }
+    for (; blk < g.ny; blk += G) {
+        const int y = row_of(blk);
+        hook.xr = rowptr(prep.x, blk + G);
+        hook.cr = rowptr(prep.corr, blk + G);
+        hook.br = rowptr(bsrc, blk + G);
+        PadLoadT<SC, true> ld{lrow, g, cc, ss, y, do_w, planes.w[0], planes.nsc};
+        double re[S::E], im[S::E];
+        int t;
+        rf_row_compute<S>(tw, ld, false, rf_lds, t, re, im, hook);
+        rf_opaque(t);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g.tpitch > 0) {
+            double2 *bcol = B + size_t(y);
+#pragma unroll
+            for (int e = 0; e < S::E; ++e)
+                if ((omask >> e) & 1u) bcol[size_t(S::out_pos(t, e)) * size_t(g.tpitch)] = make_double2(re[e], im[e]);
+        } else {
+            double2 *brow = B + size_t(y) * size_t(g.bpitch);
+#pragma unroll
+            for (int e = 0; e < S::E; ++e)
+                if ((omask >> e) & 1u) brow[S::out_pos(t, e)] = make_double2(re[e], im[e]);
+        }
+    }
+}
+
 void fused_geom_fit(FusedGeom &g)
 {
     g.npoly = 0;
@@ -1120,6 +1245,30 @@ static void launch_pad(const RowFFTPlan &pl, const FusedGeom &g, const uint8_t *
     const bool row = fused_row_fits(S::LDS_BYTES, g.nx);
     PFB_REQUIRE(row || prep.x == nullptr, "fused pad kernel without an LDS row needs a prepared image (fused_pad_takes_prep)");
     const size_t lds = size_t(S::LDS_BYTES) + (row ? size_t(g.nx) * sizeof(double) : 0);
+    {   // single-plane launches on the raw image: the persistent form (PFBHIP_PAD_PERSIST=0 keeps one workgroup per row)
+        static const bool persist = [] { const char *e = std::getenv("PFBHIP_PAD_PERSIST"); return !(e != nullptr && e[0] == '0'); }();
+        if (persist && row && planes.kp == 1 && prep.x != nullptr) {
+            int dev = 0, ncu = 256;
+            PFB_HIP(hipGetDevice(&dev));
+            PFB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+            // one workgroup per CU, a multiple of 64 of them (the row -> block map groups blocks in 64s)
+            const uint32_t nwg = uint32_t(std::min<int>(g.ny, std::max(64, (ncu / 64) * 64)));
+            const bool sc = planes.nsc > 0 && !planes.sep && do_w, beam = prep.beam != nullptr;
+            static bool ap[4] = {false, false, false, false};
+#define PFB_PADP(SCV, BV)                                                                                                        \
+    do {                                                                                                                         \
+        rf_allow_lds(&k_fused_pad_fft_p<S, SCV, BV>, &ap[(SCV ? 2 : 0) + (BV ? 1 : 0)]);                                          \
+        hipLaunchKernelGGL((k_fused_pad_fft_p<S, SCV, BV>), dim3(nwg), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, prep, planes, \
+                           do_w, B_dev);                                                                                         \
+    } while (0)
+            if (sc && beam) PFB_PADP(true, true);
+            else if (sc) PFB_PADP(true, false);
+            else if (beam) PFB_PADP(false, true);
+            else PFB_PADP(false, false);
+#undef PFB_PADP
+            return;
+        }
+    }
     if (planes.nsc > 0 && !planes.sep && do_w) {
         rf_allow_lds(&k_fused_pad_fft<S, true>, &attr_sc);
         hipLaunchKernelGGL((k_fused_pad_fft<S, true>), dim3(uint32_t(g.ny)), dim3(S::T), lds, stream, pl.twiddle, g, occ_dev, dcT_dev,

@@ -632,23 +632,43 @@ struct RfShape2 {
     }
 };
 
+// Hooks (round 4): a caller's own work interleaved with the passes of a row -- at<0>() runs when the row's inputs have been
+// consumed (after the loads / the leading odd pass), at<P + 1>() after the butterflies of pass P: S::NP + 1 points in all.  A
+// persistent kernel uses them to request the NEXT row's inputs in batches and bank them while this row's passes run: one
+// workgroup per CU otherwise serialises load phase (a CU pulls ~10 B per clock), passes and store phase.
+struct RfNoHook {
+    template <int P>
+    __device__ __forceinline__ void at() const
+    {
+    }
+};
+
 // Passes P.. of the power-of-two part; w1 holds the (already requested) twiddles of pass P.  The
 // twiddles of pass P + 1 are requested BEFORE the LDS transpose of pass P so that their L2 latency
 // hides behind it.
-template <class S, int P, int NS>
+template <class S, int P, int NS, class Hook>
 __device__ __forceinline__ void rf_passes(double (&re)[S::E], double (&im)[S::E], int t,
                                           const double2 *__restrict__ tw, double *lds,
-                                          const double2 (&w1)[S::E / rf_radix(S::K, P)])
+                                          const double2 (&w1)[S::E / rf_radix(S::K, P)], Hook &hook)
 {
     constexpr int R = rf_radix(S::K, P);
     rf_butterflies<R, S::E>(re, im, NS > 1, w1);
+    hook.template at<P + 1>();
     if constexpr (P + 1 < S::NP) {
         constexpr int R2 = rf_radix(S::K, P + 1);
         double2 w2[S::E / R2];
         rf_load_twiddles<R2, S::E>(w2, t, S::T, S::N, NS * R, tw);
         rf_transpose<R, S::E, S::DUAL, S::SWZ, S::T, S::N, NS, S::xpad(R, NS), S::NL>(re, im, t, lds);
-        rf_passes<S, P + 1, NS * R>(re, im, t, tw, lds, w2);
+        rf_passes<S, P + 1, NS * R>(re, im, t, tw, lds, w2, hook);
     }
+}
+template <class S, int P, int NS>
+__device__ __forceinline__ void rf_passes(double (&re)[S::E], double (&im)[S::E], int t,
+                                          const double2 *__restrict__ tw, double *lds,
+                                          const double2 (&w1)[S::E / rf_radix(S::K, P)])
+{
+    RfNoHook none;
+    rf_passes<S, P, NS>(re, im, t, tw, lds, w1, none);
 }
 
 // Makes the thread index opaque to the optimiser again.  Callers put it between a transform and their
@@ -677,9 +697,9 @@ struct RfHalfLoad<Load, PAR, SLOT0, true> {
 // (re[e], im[e]) for the forward transform and as (im[e], re[e]) for the (unnormalised) inverse.
 // NB: butterflies of the leading odd pass whose requests are in flight together (default: the shape's LOAD_BATCH; the doubled
 // kernels, which hold half a transform next to the running one, ask for fewer)
-template <class S, class Load, int NB = S::LOAD_BATCH>
+template <class S, class Load, int NB = S::LOAD_BATCH, class Hook = RfNoHook>
 __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, Load &ld, bool inverse, double *lds,
-                                               int &t_out, double (&re)[S::E], double (&im)[S::E])
+                                               int &t_out, double (&re)[S::E], double (&im)[S::E], Hook &&hook = Hook{})
 {
     if constexpr (S::DOUBLED) {
         using S1 = typename S::S1;
@@ -733,7 +753,8 @@ __device__ __forceinline__ void rf_row_compute(const double2 *__restrict__ tw, L
             im[e] = inverse ? x.x : x.y;
         }
     }
-    rf_passes<S, 0, S::LEAD>(re, im, t, tw, lds, w0);
+    hook.template at<0>();
+    rf_passes<S, 0, S::LEAD>(re, im, t, tw, lds, w0, hook);
     }
 }
 
