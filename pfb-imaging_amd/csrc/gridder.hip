@@ -1577,9 +1577,10 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         const size_t per_pass = work.size() / std::max<size_t>(g->work_cnt.size(), 1);
         if (info.wmode == 2) {
             PFB_REQUIRE(g->scatter_blk, "the one-plane w-scheme needs the block-ordered sort");
-            // (PFBHIP_WD_COLOURS=1: the four colour launches whatever the size -- tests)
+            // (PFBHIP_WD_COLOURS=1: the four colour launches whatever the size -- tests; 0: one launch with the atomic flush)
             const char *cenv = std::getenv("PFBHIP_WD_COLOURS");
             g->wd_small = per_pass < size_t(2048) && !(cenv != nullptr && cenv[0] == '1');
+            if (cenv != nullptr && cenv[0] == '0') g->wd_small = true;
         } else if (g->scatter_blk && smode != "block" && smode != "rec" && smode != "rec_es" && per_pass < size_t(2048)) g->scatter_blk = false;
     }
     {
