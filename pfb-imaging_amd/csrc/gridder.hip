@@ -1504,6 +1504,8 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     m.key_sub = (g->scatter_blk && nkeys * 64 < (int64_t(1) << 32) - 2) ? 64 : 1;
     g->scatter_blk = m.key_sub > 1;  // without the block order in the 32-bit key the runs are ~1 long: the walk kernel is cheaper
     std::vector<WorkItem> work;
+    uint32_t chunk_used = CHUNK;
+    size_t coarse_items = 0;  // work items at CHUNK visibilities each (the size measure of the launch-shape decisions below)
     g->work_off.clear();
     g->work_cnt.clear();
     info.nactive = 0;
@@ -1531,7 +1533,12 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         // visibilities per work item (PFBHIP_CHUNK, 256..4096): smaller items balance the launch tail, larger ones amortise
         // the per-item prologue / tile flush
         uint32_t chunk = CHUNK;
+        if (info.wmode == 2) {  // the one-plane gather (256-thread workgroups, 768 slots): about three items per slot, 512..4096 each
+            chunk = 512;
+            while (chunk < CHUNK && double(chunk) * 1.5 < double(info.nactive) / (3.0 * 768.0)) chunk *= 2;
+        }
         if (const char *cenv = std::getenv("PFBHIP_CHUNK")) chunk = uint32_t(std::max(256, std::min(int(CHUNK), std::atoi(cenv))));
+        chunk_used = chunk;
         for (int64_t grp = 0; grp < (plane_sorted ? ngroups : 1); ++grp) {
             // planes [q, q + kp) are touched by visibilities whose first plane lies in [q - W + 1, q + kp - 1]
             const int64_t q = grp * g->kp_max, kp = std::min<int64_t>(g->kp_max, info.nplanes - q);
@@ -1542,6 +1549,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
                 const uint32_t b0 = tstart[size_t(t * P + lo_p)], b1 = tstart[size_t(t * P + hi_p + 1)];
                 // a tile's visibilities in equal parts of <= chunk (4096 + 904 would leave a short item behind a long one)
                 const uint32_t nt = b1 - b0, parts = (nt + chunk - 1) / chunk;
+                coarse_items += (nt + CHUNK - 1) / CHUNK;
                 for (uint32_t q = 0; q < parts; ++q)
                     work.push_back(WorkItem{uint32_t(t), b0 + uint32_t(uint64_t(nt) * q / parts), b0 + uint32_t(uint64_t(nt) * (q + 1) / parts), 0});
             }
@@ -1570,7 +1578,8 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         g->work_cnt.push_back(0);
     }
     // Small plans (C1: ~300 work items) run faster on the single-launch walk kernel: four colour launches of a few dozen
-    // workgroups each leave most of the 256 CUs idle.  The block order of the sort is kept either way (any order is valid).
+    // workgroups each leave most of the 256 CUs idle.  (One-plane scheme, round 4 size sweep: one launch with the atomic flush
+    // wins up to 4096^2 / 4e6 visibilities = 5 000 tiles in use, ties at 6144^2 = 11 000, loses at C2 = 20 000: 2.44 vs 2.31 ms.)  The block order of the sort is kept either way (any order is valid).
     {
         // (mean over the passes: the first and last pass of an ES-plane plan hold the few visibilities at the ends of the w
         // range -- their launches are short whichever kernel runs them)
@@ -1579,7 +1588,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             PFB_REQUIRE(g->scatter_blk, "the one-plane w-scheme needs the block-ordered sort");
             // (PFBHIP_WD_COLOURS=1: the four colour launches whatever the size -- tests; 0: one launch with the atomic flush)
             const char *cenv = std::getenv("PFBHIP_WD_COLOURS");
-            g->wd_small = per_pass < size_t(2048) && !(cenv != nullptr && cenv[0] == '1');
+            g->wd_small = coarse_items / std::max<size_t>(g->work_cnt.size(), 1) < size_t(8192) && !(cenv != nullptr && cenv[0] == '1');
             if (cenv != nullptr && cenv[0] == '0') g->wd_small = true;
         } else if (g->scatter_blk && smode != "block" && smode != "rec" && smode != "rec_es" && per_pass < size_t(2048)) g->scatter_blk = false;
     }
@@ -1588,6 +1597,18 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
         // slice are flagged shared (pad = 1) and keep the atomic flush
         const int64_t ntu_c = ceil_div(info.nu, TILE);
         g->coloured = g->scatter_blk && !g->wd_small && (ntu_c % 2 == 0) && (m.ntv % 2 == 0) && info.nu % TILE == 0 && info.nv % TILE == 0;
+        // The one-plane scatter runs 256-thread workgroups: an item of 4096 visibilities is 1024 per wave, longer than a whole
+        // colour launch of a mid-size plan should take (4096^2, 4e6 visibilities: grid 1.61 ms -> 1.02 with items of <= 1024; C2
+        // indifferent between 1024 and 4096).  Its lists are cut finer than the gather's: about three items per workgroup
+        // slot and launch, 512..2048 visibilities each (PFBHIP_WD_CHUNK pins it).
+        uint32_t schunk = chunk_used;
+        if (info.wmode == 2) {
+            const double per_launch = double(info.nactive) / (g->coloured ? 4.0 : 1.0);
+            uint32_t c = 512;
+            while (c < 2048 && double(c) * 1.5 < per_launch / (3.0 * 768.0)) c *= 2;
+            if (const char *cenv = std::getenv("PFBHIP_WD_CHUNK")) c = uint32_t(std::max(64, std::min(int(CHUNK), std::atoi(cenv))));
+            schunk = std::min(c, chunk_used);
+        }
         std::vector<WorkItem> wcol;
         wcol.reserve(work.size());
         g->col_off.clear();
@@ -1604,9 +1625,18 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
                     const int c = g->coloured ? int((tu & 1u) * 2u + (tv & 1u)) : 0;
                     if (c != col) continue;
                     WorkItem w = work[i];
-                    w.pad = (!g->coloured || seen[w.tile] > 1) ? 1u : 0u;
-                    wcol.push_back(w);
+                    const uint32_t nt = w.end - w.begin, parts = (nt + schunk - 1) / schunk;
+                    w.pad = (!g->coloured || seen[w.tile] > 1 || parts > 1) ? 1u : 0u;
+                    for (uint32_t q = 0; q < std::max(parts, 1u); ++q) {
+                        WorkItem wq = w;
+                        wq.begin = w.begin + uint32_t(uint64_t(nt) * q / std::max(parts, 1u));
+                        wq.end = w.begin + uint32_t(uint64_t(nt) * (q + 1) / std::max(parts, 1u));
+                        wcol.push_back(wq);
+                    }
                 }
+                if (schunk < chunk_used)  // (the finer split interleaves the parts of neighbouring items: heaviest first again)
+                    std::stable_sort(wcol.begin() + std::ptrdiff_t(g->col_off.back()), wcol.end(),
+                                     [](const WorkItem &x, const WorkItem &y) { return (x.end - x.begin) > (y.end - y.begin); });
                 g->col_cnt.push_back(wcol.size() - g->col_off.back());
             }
         }
