@@ -794,6 +794,33 @@ def test_one_plane_w_scheme(K, widen, eps, npix, monkeypatch):
     g2.close()
 
 
+@pytest.mark.parametrize("env", [dict(PFBHIP_WD_COLOURS="1", PFBHIP_WD_CHUNK="64"), dict(PFBHIP_WD_COLOURS="0", PFBHIP_WD_CHUNK="96"),
+                                 dict(PFBHIP_CHUNK="256", PFBHIP_WD_COLOURS="1")])
+def test_one_plane_work_item_sizes(env, monkeypatch):
+    """The one-plane scheme sizes its work items to the launch (csrc/gridder.hip: the gather's items, and the scatter's colour
+    lists cut finer from them, parts of one tile flagged shared -> atomic tile flush): however the lists are cut, the results are
+    those of the default cut up to the order of the additions."""
+    c = synth.make_case(60000, 2, 512, zscale=1e-3, seed=8)
+    cell = c["cell"] * 16.0
+    x = np.ascontiguousarray(c["x"])
+
+    def run():
+        g, kw, mask = gpu_plan(c, npix_x=512, npix_y=512, pixsize_x=cell, pixsize_y=cell, epsilon=1e-7, force_wmode=2)
+        assert g.info["wmode"] == 2
+        g.set_weights(c["wgt"])
+        out = g.vis2dirty(c["vis"], c["wgt"]), g.dirty2vis(x), g.hessian(x, eta=0.1, wsum=3.0), g.info["scatter_launches"]
+        g.close()
+        return out
+
+    d0, v0, h0, _ = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    d1, v1, h1, nl = run()
+    assert nl == (4 if env.get("PFBHIP_WD_COLOURS") == "1" else 1)
+    # (the order of the additions into a cell changes with the cut; the image-side correction amplifies that rounding: 6e-12 seen)
+    assert rel(d1, d0) < 1e-10 and rel(v1, v0) < 1e-10 and rel(h1, h0) < 1e-10
+
+
 def test_apply_graph_replay(monkeypatch):
     """PFBHIP_GRAPH=1: the Hessian apply replayed from a captured hipGraph (csrc/gridder.hip: hessian_dev_impl): the first call with
     a set of buffers runs eagerly, the second captures, later ones replay -- with new contents of x, new weights, and in the
