@@ -442,6 +442,8 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
         names = dict(KERNEL_OF)
         if info["wmode"] == 2:
             names.update({"grid": "k_grid_wd", "degrid": "k_degrid_wd"})
+            if os.environ.get("PFBHIP_PAD_PERSIST", "1") != "0" and info["fft_mode"] & 8:
+                names["pad_fft"] = "k_fused_pad_fft_p"   # the single plane's persistent pad kernel (csrc/rowfft.hip)
         elif info["scatter_mode"] != 2:
             names["grid"] = "k_grid_blk" if info["scatter_mode"] == 1 else "k_grid_mp"
         if not info["fft_mode"] & 8:
