@@ -1292,7 +1292,11 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
                 const double own_pt = (nu > 16384 || nv > 16384) ? 3.7e-11 : 2.7e-11;
                 const double plane_cost = own ? own_pt * double(nu) * double(nv)
                                               : 1.2 * (fft2d_seconds(nu, nv) + 3.0 * 16.0 * double(nu) * double(nv) / 5.0e12);
-                const double gridcost = nvis * double(nder > 0 ? touched : std::min<int64_t>(touched, npl)) * 0.30e-9;
+                double gridcost = nvis * double(nder > 0 ? touched : std::min<int64_t>(touched, npl)) * 0.30e-9;
+                // (one-plane scatter: a lane holds ceil((W + 3) / 3) rows of the block frame and reads that many kernel entries
+                // per visibility from LDS -- 7 at W = 16, 6 at W = 13..15: measured at C2, W = 15 against 16: grid 2.27 against
+                // 2.38 ms, the gather indifferent)
+                if (nder > 0) gridcost *= 0.82 + 0.03 * double((r.W + 3 + 2) / 3);
                 const double cost = double(npl) * plane_cost + gridcost;
                 // cheapest wins; within 1 % the more accurate row does (W is free up to 16, so the best row
                 // that maps to the same grid and plane count usually beats the requested epsilon)
