@@ -186,6 +186,12 @@ int pfbhip_gridder_hessian(pfbhip_gridder *g, const double *x_host, const double
                            double *out_host);
 int pfbhip_gridder_hessian_dev(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta,
                                double wsum, double *out_dev);
+/* The exact residual of one partition with every image resident in HBM: out = acc - R^H W R (beam * model)
+ * (src/pfb_imaging/operators/gridder.py:962-1016: dirty2vis of beam * model, vis2dirty with the imaging weights, subtracted
+ * from the dirty image; band_worker.py:167-182 calls it per band).  Weights as bound by set_weights; beam may be NULL; out may
+ * be acc (chains over the partitions of a band) but not model. */
+int pfbhip_gridder_residual_dev(pfbhip_gridder *g, const double *model_dev, const double *beam_dev, const double *acc_dev,
+                                double *out_dev);
 /* Device-resident single directions (bench / on-device solvers).  vis_sorted_dev
  * holds nactive complex values in the handle's tile-sorted order. */
 /* vis2dirty with the image left in HBM (row-sharded single band: the partial images are summed over xGMI before one download) */

@@ -6,6 +6,7 @@ no fallback: if it is missing, importing any operator raises ImportError telling
 
 import ctypes as ct
 import os
+import threading
 
 import numpy as np
 
@@ -72,7 +73,7 @@ SYMBOLS = (
     "pfbhip_gridder_create", "pfbhip_gridder_destroy", "pfbhip_gridder_get_info", "pfbhip_gridder_get_binmap",
     "pfbhip_gridder_get_planes",
     "pfbhip_gridder_vis2dirty", "pfbhip_gridder_vis2dirty_dev", "pfbhip_gridder_dirty2vis", "pfbhip_gridder_grid_plane",
-    "pfbhip_gridder_set_weights", "pfbhip_gridder_hessian", "pfbhip_gridder_hessian_dev",
+    "pfbhip_gridder_set_weights", "pfbhip_gridder_hessian", "pfbhip_gridder_hessian_dev", "pfbhip_gridder_residual_dev",
     "pfbhip_gridder_vis2dirty_sp", "pfbhip_gridder_dirty2vis_sp", "pfbhip_gridder_set_weights_sp", "pfbhip_gridder_hessian_sp",
     "pfbhip_gridder_degrid_dev", "pfbhip_gridder_grid_dev", "pfbhip_gridder_profile", "pfbhip_gridder_profile_get",
     "pfbhip_gridder_debug_stamps",
@@ -134,6 +135,17 @@ def device_count():
     return n.value
 
 
+def get_device():
+    """The HIP device of the CALLING thread (HIP keeps one current device per host thread; new threads start on device 0)."""
+    d = cint(0)
+    check(lib().pfbhip_get_device(ct.byref(d)))
+    return d.value
+
+
+def set_device(device):
+    check(lib().pfbhip_set_device(cint(int(device))))
+
+
 def device_cache(flush=False):
     """Bytes of released device blocks the library keeps for the next plan of the same sizes (``pfbhip_device_cache``);
     ``flush=True`` returns them to the driver.  Returns the cached bytes before the flush."""
@@ -173,6 +185,8 @@ _PINNED_MIN_BYTES = 1 << 20
 # DIRTY / PSF cubes of many bands would otherwise lock tens of GB.  Past the cap (PFBHIP_PINNED_MAX_MB; default a quarter of
 # the physical memory, at least 4 GiB) results are ordinary pageable numpy arrays -- slower device-to-host copies, nothing else.
 _pinned_live = [0]
+# (BandWorkerPool runs its bands on threads, and finalizers run wherever the collector happens to: one re-entrant lock over the pool)
+_pinned_lock = threading.RLock()
 
 
 def _pinned_cap():
@@ -202,12 +216,34 @@ def _pinned_trim(limit):
 
 
 def _pinned_release(addr, nbytes):
-    if nbytes > _PINNED_POOL_BYTES:
-        _pinned_free(addr, nbytes)
-        return
-    _pinned_pool.append((nbytes, addr))
-    _pinned_pooled[0] += nbytes
-    _pinned_trim(_PINNED_POOL_BYTES)
+    with _pinned_lock:
+        if nbytes > _PINNED_POOL_BYTES:
+            _pinned_free(addr, nbytes)
+            return
+        _pinned_pool.append((nbytes, addr))
+        _pinned_pooled[0] += nbytes
+        _pinned_trim(_PINNED_POOL_BYTES)
+
+
+def _pinned_take(nbytes):
+    """Address of a page-locked buffer of ``nbytes`` (pooled or new), or None when the cap or the allocator says no.  Caller
+    holds ``_pinned_lock``."""
+    for i in range(len(_pinned_pool) - 1, -1, -1):  # newest first
+        if _pinned_pool[i][0] == nbytes:
+            addr = _pinned_pool.pop(i)[1]
+            _pinned_pooled[0] -= nbytes
+            return addr
+    if _pinned_live[0] + nbytes > _pinned_cap():
+        _pinned_trim(0)  # idle buffers first
+        if _pinned_live[0] + nbytes > _pinned_cap():
+            return None
+    p = vp()
+    if lib().pfbhip_host_alloc(ct.byref(p), ct.c_size_t(nbytes)) != 0:
+        _pinned_trim(0)
+        if lib().pfbhip_host_alloc(ct.byref(p), ct.c_size_t(nbytes)) != 0:
+            return None
+    _pinned_live[0] += nbytes
+    return p.value
 
 
 def result_empty(shape, dtype):
@@ -222,24 +258,10 @@ def result_empty(shape, dtype):
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if nbytes < _PINNED_MIN_BYTES or os.environ.get("PFBHIP_PINNED_RESULTS", "1") == "0":
         return np.empty(shape, dtype=dtype)
-    addr = None
-    for i in range(len(_pinned_pool) - 1, -1, -1):  # newest first
-        if _pinned_pool[i][0] == nbytes:
-            addr = _pinned_pool.pop(i)[1]
-            _pinned_pooled[0] -= nbytes
-            break
+    with _pinned_lock:
+        addr = _pinned_take(nbytes)
     if addr is None:
-        if _pinned_live[0] + nbytes > _pinned_cap():
-            _pinned_trim(0)  # idle buffers first
-            if _pinned_live[0] + nbytes > _pinned_cap():
-                return np.empty(shape, dtype=dtype)
-        p = vp()
-        if lib().pfbhip_host_alloc(ct.byref(p), ct.c_size_t(nbytes)) != 0:
-            _pinned_trim(0)
-            if lib().pfbhip_host_alloc(ct.byref(p), ct.c_size_t(nbytes)) != 0:
-                return np.empty(shape, dtype=dtype)
-        addr = p.value
-        _pinned_live[0] += nbytes
+        return np.empty(shape, dtype=dtype)
     buf = (ct.c_char * nbytes).from_address(addr)
     weakref.finalize(buf, _pinned_release, addr, nbytes)  # runs when the last array / view over `buf` is gone
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
@@ -294,6 +316,7 @@ _ro_memo = {}  # (address, shape, dtype) -> (array kept alive, key, sample): rea
 _RO_MEMO_MAX = 32
 _RO_MEMO_BYTES = int(os.environ.get("PFBHIP_RO_MEMO_MB", "4096")) << 20  # bound on the bytes the memo keeps alive
 _ro_memo_bytes = [0]
+_ro_lock = threading.Lock()
 
 
 def _immutable(a):
@@ -335,20 +358,23 @@ def content_key(a):
     ro = a.flags.c_contiguous and _immutable(a)
     if ro:
         mk = (a.ctypes.data, a.shape, a.dtype.str)
-        hit = _ro_memo.get(mk)
-        if hit is not None:
-            if hit[2] == _sample(a):
-                return hit[1]
-            _ro_memo_bytes[0] -= hit[0].nbytes
-            del _ro_memo[mk]
+        with _ro_lock:
+            hit = _ro_memo.get(mk)
+            if hit is not None:
+                if hit[2] == _sample(a):
+                    return hit[1]
+                _ro_memo_bytes[0] -= hit[0].nbytes
+                del _ro_memo[mk]
     c = np.ascontiguousarray(a)
     key = (c.shape, c.dtype.str, int(lib().pfbhip_hash64(c.ctypes.data_as(ct.c_void_p), ct.c_size_t(c.nbytes))))
     if ro and a.nbytes <= _RO_MEMO_BYTES:
-        while _ro_memo and (len(_ro_memo) >= _RO_MEMO_MAX or _ro_memo_bytes[0] + a.nbytes > _RO_MEMO_BYTES):
-            old = _ro_memo.pop(next(iter(_ro_memo)))
-            _ro_memo_bytes[0] -= old[0].nbytes
-        _ro_memo[mk] = (a, key, _sample(a))  # holding `a` keeps its buffer from being freed and the address from being reused
-        _ro_memo_bytes[0] += a.nbytes
+        with _ro_lock:
+            if mk not in _ro_memo:
+                while _ro_memo and (len(_ro_memo) >= _RO_MEMO_MAX or _ro_memo_bytes[0] + a.nbytes > _RO_MEMO_BYTES):
+                    old = _ro_memo.pop(next(iter(_ro_memo)))
+                    _ro_memo_bytes[0] -= old[0].nbytes
+                _ro_memo[mk] = (a, key, _sample(a))  # holding `a` keeps its buffer from being freed and the address from being reused
+                _ro_memo_bytes[0] += a.nbytes
     return key
 
 

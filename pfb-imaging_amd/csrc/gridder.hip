@@ -2383,6 +2383,8 @@ int pfbhip_gridder_set_weights(pfbhip_gridder *g, const double *wgt_host)
 
 static void hessian_dev_eager(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta, double wsum,
                               double *out_dev);
+static void apply_eager(pfbhip_gridder *g, const double *x_dev, const double *beam_in_dev, const double *beam_out_dev, double scale,
+                        double eta, const double *addend_dev, double *out_dev);
 
 // The apply, replayed from a captured graph where that pays (see pfbhip_gridder::ApplyGraph).
 static void hessian_dev_impl(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta, double wsum,
@@ -2444,6 +2446,13 @@ static void hessian_dev_impl(pfbhip_gridder *g, const double *x_dev, const doubl
 static void hessian_dev_eager(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta, double wsum,
                               double *out_dev)
 {
+    apply_eager(g, x_dev, beam_dev, beam_dev, wsum > 0.0 ? 1.0 / wsum : 1.0, eta, eta != 0.0 ? x_dev : nullptr, out_dev);
+}
+
+// out = beam_out * R^H W R (beam_in * x) * scale + eta * addend   (every image resident in HBM; beams and addend may be NULL)
+static void apply_eager(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, const double *beam_out_dev, double scale,
+                        double eta, const double *addend_dev, double *out_dev)
+{
     PFB_REQUIRE(g->weights_bound, "call pfbhip_gridder_set_weights before the Hessian");
     hipStream_t st = g->stream;
     const int64_t npix = g->prm.nx * g->prm.ny;
@@ -2484,8 +2493,22 @@ static void hessian_dev_eager(pfbhip_gridder *g, const double *x_dev, const doub
             g->planes_cleared = false;
         }
     } restore{g};
-    g->grid_and_finalize(g->d_sval.p, beam_dev, wsum > 0.0 ? 1.0 / wsum : 1.0, eta, eta != 0.0 ? x_dev : nullptr, out_dev);
+    g->grid_and_finalize(g->d_sval.p, beam_out_dev, scale, eta, (eta != 0.0) ? addend_dev : nullptr, out_dev);
     (void)npix;
+}
+
+// The exact residual of one partition (gridder.py:962-1016 of the reference: dirty2vis of beam * model, vis2dirty with the
+// imaging weights, subtracted from the dirty image): out = acc - R^H W R (beam * model), every image resident in HBM -- the
+// subtraction is the eta * addend term of the fused second-axis kernel's epilogue (scale -1, eta 1), not another pass.
+int pfbhip_gridder_residual_dev(pfbhip_gridder *g, const double *model_dev, const double *beam_dev, const double *acc_dev,
+                                double *out_dev)
+{
+    return guarded([&] {
+        PFB_REQUIRE(g && model_dev && acc_dev && out_dev, "NULL argument");
+        PFB_REQUIRE(model_dev != out_dev, "the residual cannot overwrite the model image");
+        apply_eager(g, model_dev, beam_dev, nullptr, -1.0, 1.0, acc_dev, out_dev);
+        PFB_HIP(hipStreamSynchronize(g->stream));
+    });
 }
 
 int pfbhip_gridder_hessian_dev(pfbhip_gridder *g, const double *x_dev, const double *beam_dev, double eta, double wsum,

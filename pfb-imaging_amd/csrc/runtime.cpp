@@ -380,14 +380,22 @@ int pfbhip_free(void *ptr_dev)
 int pfbhip_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes)
 {
     return guarded([&] {
-        if (bytes) PFB_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+        // (the calling thread's own stream, then wait: copies issued by the band pool's threads do not queue behind one
+        // another on the device's single null stream, and the two PCIe directions overlap across bands)
+        if (bytes) {
+            PFB_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, hipStreamPerThread));
+            PFB_HIP(hipStreamSynchronize(hipStreamPerThread));
+        }
     });
 }
 
 int pfbhip_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes)
 {
     return guarded([&] {
-        if (bytes) PFB_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+        if (bytes) {
+            PFB_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, hipStreamPerThread));
+            PFB_HIP(hipStreamSynchronize(hipStreamPerThread));
+        }
     });
 }
 

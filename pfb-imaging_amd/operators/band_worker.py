@@ -96,7 +96,7 @@ class _BandWorkerImpl:
         return self._hess.cg(rhs, x0=x0, tol=tol, maxit=maxit, minit=minit)
 
     # --- exact residual role ---
-    def residual(self, model, cell_rad, epsilon, do_wgridding, double_accum):
+    def residual(self, model, cell_rad, epsilon, do_wgridding, double_accum, out=None):
         from .gridder import PartitionResidual
 
         ncorr, nx, ny = self._dirty.shape
@@ -107,8 +107,11 @@ class _BandWorkerImpl:
             self._resid = PartitionResidual(self._parts, nx, ny, cell_rad, epsilon=epsilon, do_wgridding=do_wgridding)
             self._resid_key = key
         if not _lib.any_nonzero(model):
-            return self._dirty - np.zeros_like(self._dirty)
-        return self._dirty - self._resid.convim(model)
+            if out is None:
+                return self._dirty - np.zeros_like(self._dirty)
+            out[...] = self._dirty
+            return out
+        return self._resid.residual(self._dirty, model, out=out)
 
     # --- wavelet role (band_worker.py:144-163) ---
     def init_psi(self, nx, ny, bases, nlevel):
@@ -155,10 +158,48 @@ class BandWorkerPool:
         self.local = local_bands(nband, rank, world)
         self.workers = {b: worker_cls(self.nthreads_per_band) for b in self.local}
         self.actors = None  # no Ray
+        import inspect
+
+        self._residual_takes_out = "out" in inspect.signature(worker_cls.residual).parameters
+        # The reference dispatches a method to every band's actor at once and gathers (band_worker.py:239-246).  Here the
+        # local bands run on host threads: every band's handle owns its HIP stream and its buffers and the C calls release
+        # the GIL, so one band's transfers overlap another's kernels -- and the two PCIe directions each other
+        # (PFBHIP_BAND_THREADS, default 4; 1 = one band after the other).
+        nthr = min(len(self.local), max(int(os.environ.get("PFBHIP_BAND_THREADS", "4")), 1))
+        self._exec = None
+        if nthr > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            # HIP's current device is per host thread and new threads start on device 0: bind them to this thread's device
+            # (worker classes of the CPU tests run without a GPU: nothing to bind)
+            bind = dict(initializer=_lib.set_device, initargs=(_lib.get_device(),)) if _lib.device_count() > 0 else {}
+            self._exec = ThreadPoolExecutor(max_workers=nthr, thread_name_prefix="pfbhip-band", **bind)
 
     def _map(self, method, per_band_args):
         """Run ``method(*args)`` on every LOCAL band worker; returns {band: result}."""
-        return {b: getattr(self.workers[b], method)(*per_band_args[b]) for b in self.local}
+        if self._exec is None:
+            return {b: getattr(self.workers[b], method)(*per_band_args[b]) for b in self.local}
+        futs = {b: self._exec.submit(getattr(self.workers[b], method), *per_band_args[b]) for b in self.local}
+        out, err = {}, None
+        for b, f in futs.items():  # every band finishes before an error propagates: no call is left running behind it
+            try:
+                out[b] = f.result()
+            except BaseException as e:  # noqa: BLE001 -- re-raised below
+                err = err or e
+        if err is not None:
+            raise err
+        return out
+
+    def close(self):
+        if self._exec is not None:
+            self._exec.shutdown(wait=True)
+            self._exec = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _exchange(self, cube):
         """Every band of ``cube`` was filled by exactly one rank (zeros elsewhere).  When every rank owns the same number of
@@ -240,11 +281,18 @@ class BandWorkerPool:
     # --- exact residual role ---
     def residual(self, model, cell_rad, epsilon=1e-7, do_wgridding=True, double_accum=True):
         """Exact per-band residual for a ``(nband, corr, nx, ny)`` model cube."""
+        # every band's result comes down straight into its slice of ONE page-locked cube (no zero-filled cube, no copy of the
+        # band images on the host: at 8192^2 that copy cost as much as the residual itself)
+        out = _lib.result_empty(model.shape, np.float64)
+        for b in range(self.nband):
+            if b not in self.workers:
+                out[b] = 0.0
         args = [(model[b], cell_rad, epsilon, do_wgridding, double_accum) for b in range(self.nband)]
-        res = self._map("residual", args)
-        out = np.zeros(model.shape, dtype=np.float64)
-        for b, r in res.items():
-            out[b] = r
+        if self._residual_takes_out:
+            self._map("residual", [a + (out[b],) for b, a in enumerate(args)])
+        else:  # (a worker class without the out argument: its arrays are copied in)
+            for b, r in self._map("residual", args).items():
+                out[b] = r
         return self._exchange(out)
 
     def residual_mfs(self, model, cell_rad, wsum, epsilon=1e-7, do_wgridding=True, double_accum=True, root=0):

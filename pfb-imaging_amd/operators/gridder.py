@@ -171,6 +171,7 @@ class PartitionResidual:
     def __init__(self, parts, nx, ny, cell_rad, epsilon=1e-7, do_wgridding=True):
         self.nx, self.ny = nx, ny
         self.items = []
+        self._beams_dev = self._m_dev = self._a_dev = None
         for part in parts:
             uvw, wgt, mask = _field(part, "UVW"), _field(part, "WEIGHT"), _field(part, "MASK")
             freq, beam = _field(part, "FREQ"), _field(part, "BEAM")
@@ -194,10 +195,44 @@ class PartitionResidual:
                 out[c] += g.hessian(beam[c] * model[c], beam=None, eta=0.0, wsum=0.0)
         return out
 
+    def residual(self, dirty, model, out=None):
+        """``dirty - convim(model)`` with the chain over the partitions on the device: per correlation the model and the
+        dirty image go up once, every partition subtracts its ``R^H W R (beam * model)`` in the epilogue of its own apply
+        (``pfbhip_gridder_residual_dev``), and the result comes down once -- no image-sized numpy pass on the host.  The
+        beams stay resident in HBM from the first call on.  ``out`` (C-contiguous float64, e.g. a band of the caller's
+        page-locked cube) receives the result in place."""
+        ncorr = model.shape[0]
+        shape = (self.nx, self.ny)
+        if out is not None and (out.shape != (ncorr,) + shape or out.dtype != np.float64 or not out.flags.c_contiguous):
+            raise ValueError("out must be a C-contiguous float64 array of the model's shape")
+        if not self.items:
+            if out is None:
+                return dirty - np.zeros_like(dirty)
+            out[...] = dirty
+            return out
+        if self._beams_dev is None:
+            self._beams_dev = [[_lib.DeviceArray.from_host(np.ascontiguousarray(beam[c], dtype=np.float64)) for c in range(beam.shape[0])]
+                               for _, _, beam in self.items]
+            self._m_dev, self._a_dev = _lib.DeviceArray(shape, np.float64), _lib.DeviceArray(shape, np.float64)
+        if out is None:
+            out = _lib.result_empty((ncorr,) + shape, np.float64)
+        for c in range(ncorr):
+            self._m_dev.upload(model[c])
+            self._a_dev.upload(dirty[c])
+            for (g, wgt, _), beams in zip(self.items, self._beams_dev):
+                g.set_weights(wgt[c])
+                g.residual_dev(self._m_dev, self._a_dev, self._a_dev, beam_dev=beams[c])
+            self._a_dev.download(out[c])
+        return out
+
     def close(self):
         for g, _, _ in self.items:
             g.close()
         self.items = []
+        for d in [b for row in (self._beams_dev or []) for b in row] + [self._m_dev, self._a_dev]:
+            if d is not None:
+                d.free()
+        self._beams_dev = self._m_dev = self._a_dev = None
 
 
 def residual_from_partitions(dirty, parts, model, cell_rad, nthreads=1, epsilon=1e-7, do_wgridding=True,

@@ -174,6 +174,12 @@ class Gridder:
         check(lib().pfbhip_gridder_hessian_dev(self._h, x_dev.ptr, None if beam_dev is None else beam_dev.ptr,
                                                f64(eta or 0.0), f64(wsum or 0.0), out_dev.ptr))
 
+    def residual_dev(self, model_dev, acc_dev, out_dev, beam_dev=None):
+        """``out = acc - R^H W R (beam * model)`` with every image a ``DeviceArray`` (``out`` may be ``acc``): the exact
+        residual of one partition, weights as bound by :meth:`set_weights`."""
+        check(lib().pfbhip_gridder_residual_dev(self._h, model_dev.ptr, None if beam_dev is None else beam_dev.ptr, acc_dev.ptr,
+                                                out_dev.ptr))
+
     def degrid_dev(self, dirty_dev, vis_sorted_dev):
         check(lib().pfbhip_gridder_degrid_dev(self._h, dirty_dev.ptr, vis_sorted_dev.ptr))
 

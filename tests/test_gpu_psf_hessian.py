@@ -451,3 +451,57 @@ def test_power_method_with_communicator():
     comm.close()
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1] == 12
     assert np.array_equal(out[0][2], out[1][2])
+
+
+def test_band_pool_threads_match_one_band_after_the_other(monkeypatch):
+    """The pool dispatches a method to all its bands at once like the reference's actors (band_worker.py:239-246); here the local
+    bands run on host threads over their own HIP streams.  Same results as one band after the other (PFBHIP_BAND_THREADS=1),
+    for the exact residual, the Hessian role and the wavelet role; an error in one band surfaces after the others finished."""
+    from pfb_imaging_amd.operators.band_worker import BandWorkerPool
+
+    nband, nx, ny, nxp, nyp = 4, 96, 80, 192, 160
+    rng = np.random.default_rng(21)
+
+    def part(seed):
+        r = np.random.default_rng(seed)
+        n = 4000
+        return {"UVW": r.standard_normal((n, 3)) * 150.0, "FREQ": np.array([1.0e9, 1.05e9, 1.1e9]),
+                "WEIGHT": np.abs(r.standard_normal((1, n, 3))) + 0.1, "MASK": (r.random((n, 3)) > 0.1).astype(np.uint8),
+                "BEAM": 0.5 + r.random((1, nx, ny)), "attrs": {"l0": 0.0, "m0": 0.0}}
+
+    parts = [[part(10 * b + 1), part(10 * b + 2)] for b in range(nband)]
+    ppb = [_tree_parts(nx, ny, nxp, nyp, 2, 1, 40 + b) for b in range(nband)]
+    dirty = rng.standard_normal((nband, 1, nx, ny))
+    model = rng.standard_normal((nband, 1, nx, ny))
+    x = rng.standard_normal((nband, nx, ny))
+
+    def run():
+        pool = BandWorkerPool(nband)
+        pool.set_bands(dirty, parts)
+        res = pool.residual(model, 2.0e-6)
+        pool.init_hess(ppb, nx, ny, nxp, nyp, np.full(nband, 0.2), np.full(nband, 5.0))
+        hd = pool.hess_dot(x)
+        nxm, nym = pool.init_psi(nx, ny, ["self", "db2"], 2)
+        al = np.zeros((nband, 2, nxm, nym))
+        pool.psi_dot(x, al)
+        xo = np.zeros((nband, nx, ny))
+        pool.psi_hdot(al, xo)
+        threaded = pool._exec is not None
+        pool.close()
+        return res, hd, al, xo, threaded
+
+    a = run()
+    assert a[4]
+    monkeypatch.setenv("PFBHIP_BAND_THREADS", "1")
+    b = run()
+    assert not b[4]
+    for u, v in zip(a[:4], b[:4]):  # (the atomic tile flush of small plans adds in whatever order the workgroups finish)
+        assert rel(u, v) < 1e-10
+    monkeypatch.delenv("PFBHIP_BAND_THREADS")
+    pool = BandWorkerPool(nband)
+    pool.set_bands(dirty, parts)
+    with pytest.raises(Exception):
+        pool.residual(model[:, :, :5], 2.0e-6)  # wrong image shape in every band: the first error is raised, no thread left behind
+    assert pool.residual(model, 2.0e-6).shape == model.shape
+    pool.close()
+
