@@ -122,13 +122,15 @@ class _BandWorkerImpl:
         self._xo = np.empty((nx, ny))
         return int(self._psib.nxmax), int(self._psib.nymax)
 
-    def psi_dot(self, x):
-        self._psib.dot(x, self._alphao)
-        return self._alphao
+    def psi_dot(self, x, out=None):
+        out = self._alphao if out is None else out
+        self._psib.dot(x, out)
+        return out
 
-    def psi_hdot(self, alpha):
-        self._psib.hdot(alpha, self._xo)
-        return self._xo
+    def psi_hdot(self, alpha, out=None):
+        out = self._xo if out is None else out
+        self._psib.hdot(alpha, out)
+        return out
 
     # --- telemetry ---
     def get_mem(self):
@@ -161,6 +163,7 @@ class BandWorkerPool:
         import inspect
 
         self._residual_takes_out = "out" in inspect.signature(worker_cls.residual).parameters
+        self._psi_takes_out = all("out" in inspect.signature(getattr(worker_cls, m)).parameters for m in ("psi_dot", "psi_hdot"))
         # The reference dispatches a method to every band's actor at once and gathers (band_worker.py:239-246).  Here the
         # local bands run on host threads: every band's handle owns its HIP stream and its buffers and the C calls release
         # the GIL, so one band's transfers overlap another's kernels -- and the two PCIe directions each other
@@ -257,17 +260,30 @@ class BandWorkerPool:
         self._psi_shape = shape
         return self._psi_shape
 
+    def _band_cube(self, method, inputs, target):
+        """``method(inputs[b])`` of every local band, written straight into ``target[b]`` when no exchange follows (one
+        process holds every band and the caller's array can take the results in place), else into a page-locked cube that
+        the exchange completes."""
+        solo = (self.comm is None or self.comm.world_size == 1) and target.dtype == np.float64 and target.flags.c_contiguous \
+            and self._psi_takes_out
+        out = target if solo else _lib.result_empty(target.shape, np.float64)
+        if not solo:
+            for b in range(self.nband):
+                if b not in self.workers:
+                    out[b] = 0.0
+        if self._psi_takes_out:
+            self._map(method, [(inputs[b], out[b]) for b in range(self.nband)])
+        else:
+            for b, res in self._map(method, [(inputs[b],) for b in range(self.nband)]).items():
+                out[b] = res
+        if not solo:
+            target[...] = self._exchange(out)
+
     def psi_dot(self, x, alphao):
-        out = np.zeros(alphao.shape, dtype=np.float64)
-        for b, res in self._map("psi_dot", [(x[b],) for b in range(self.nband)]).items():
-            out[b] = res
-        alphao[...] = self._exchange(out)
+        self._band_cube("psi_dot", x, alphao)
 
     def psi_hdot(self, alpha, xo):
-        out = np.zeros(xo.shape, dtype=np.float64)
-        for b, res in self._map("psi_hdot", [(alpha[b],) for b in range(self.nband)]).items():
-            out[b] = res
-        xo[...] = self._exchange(out)
+        self._band_cube("psi_hdot", alpha, xo)
 
     def dual_update(self, vp, v, lam, sigma=1.0, weight=None):
         """``dual_update_numba_fast`` (prox/prox_21m.py:105-135) over cubes ``(nband, nbasis, n1, n2)``, in place

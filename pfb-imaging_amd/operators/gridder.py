@@ -245,10 +245,9 @@ def residual_from_partitions(dirty, parts, model, cell_rad, nthreads=1, epsilon=
         return dirty - np.zeros_like(dirty)
     state = PartitionResidual(parts, nx, ny, cell_rad, epsilon=epsilon, do_wgridding=do_wgridding)
     try:
-        convim = state.convim(model)
+        return state.residual(np.ascontiguousarray(dirty, dtype=np.float64), model)
     finally:
         state.close()
-    return dirty - convim
 
 
 def compute_residual_arrays(dirty, model, uvw, freq, wgt, mask, beam, cell_rad, x0=0.0, y0=0.0, flip_u=False,

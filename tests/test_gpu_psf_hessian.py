@@ -254,9 +254,15 @@ def test_band_pool_residual_and_mfs():
     pool.set_bands(dirty, parts)
     res = pool.residual(model, 1.0e-6)
     assert res.shape == (nband, 1, nx, ny)
+    from pfb_imaging_amd.operators.gridder import PartitionResidual
+
     for b in range(nband):
         np.testing.assert_allclose(res[b], residual_from_partitions(dirty[b], parts[b], model[b], 1.0e-6), rtol=1e-9,
                                    atol=1e-9)
+        # the device chain over the partitions (pfbhip_gridder_residual_dev) against the sum of the partitions' host-side applies
+        st = PartitionResidual(parts[b], nx, ny, 1.0e-6)
+        np.testing.assert_allclose(res[b], dirty[b] - st.convim(model[b]), rtol=1e-9, atol=1e-9)
+        st.close()
     mfs = pool.residual_mfs(model, 1.0e-6, wsum=3.0)
     np.testing.assert_allclose(mfs, res.sum(axis=0) / 3.0, rtol=1e-12, atol=1e-12)
     assert pool.init_psi(nx, ny, ["self"], 2) == (nx, ny)  # the wavelet role (tests/test_gpu_psi.py)
