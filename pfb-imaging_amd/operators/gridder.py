@@ -258,12 +258,23 @@ def compute_residual_arrays(dirty, model, uvw, freq, wgt, mask, beam, cell_rad, 
     g = Gridder(uvw, freq, mask, npix_x=nx, npix_y=ny, pixsize_x=cell_rad, pixsize_y=cell_rad, center_x=x0,
                 center_y=y0, epsilon=epsilon, flip_u=flip_u, flip_v=flip_v, flip_w=flip_w, do_wgridding=do_wgridding,
                 divide_by_n=False, sigma_min=1.1, sigma_max=3.0)
+    devs = []
     try:
-        residual = np.empty_like(dirty)
+        # dirty - R^H W R (beam * model) in one device call per correlation: the beam is applied by the degridding side's
+        # prepare step and the subtraction by the apply's last kernel (pfbhip_gridder_residual_dev)
+        residual = _lib.result_empty(dirty.shape, np.float64)
+        devs = [_lib.DeviceArray((nx, ny), np.float64) for _ in range(3)]
+        m_dev, b_dev, a_dev = devs
         for c in range(ncorr):
             g.set_weights(wgt[c])
-            residual[c] = dirty[c] - g.hessian(beam[c] * model[c])
+            m_dev.upload(model[c])
+            b_dev.upload(beam[c])
+            a_dev.upload(dirty[c])
+            g.residual_dev(m_dev, a_dev, a_dev, beam_dev=b_dev)
+            a_dev.download(residual[c])
     finally:
+        for d in devs:
+            d.free()
         g.close()
     return residual
 
