@@ -88,8 +88,8 @@ class _BandWorkerImpl:
                 raise RuntimeError("no partitions passed and none loaded; call load_band first")
         self._hess = HessianTree(partitions, nx, ny, nx_psf, ny_psf, eta=eta, nthreads=self._nthreads, wsum=wsum)
 
-    def hess_dot(self, x):
-        return self._hess.dot(x)
+    def hess_dot(self, x, out=None):
+        return self._hess.dot(x, out=out)
 
     def cg(self, rhs, x0, tol, maxit, minit, verbosity):
         # whole solve on the device; x0 is copied (Ray-style read-only inputs are never written)
@@ -163,6 +163,7 @@ class BandWorkerPool:
         import inspect
 
         self._residual_takes_out = "out" in inspect.signature(worker_cls.residual).parameters
+        self._hess_takes_out = "out" in inspect.signature(worker_cls.hess_dot).parameters
         self._psi_takes_out = all("out" in inspect.signature(getattr(worker_cls, m)).parameters for m in ("psi_dot", "psi_hdot"))
         # The reference dispatches a method to every band's actor at once and gathers (band_worker.py:239-246).  Here the
         # local bands run on host threads: every band's handle owns its HIP stream and its buffers and the C calls release
@@ -239,9 +240,15 @@ class BandWorkerPool:
                                  ny_psf, etas[b], wsums[b]) for b in range(self.nband)])
 
     def hess_dot(self, x):
-        out = np.zeros_like(x, dtype=np.float64)
-        for b, res in self._map("hess_dot", [(x[b],) for b in range(self.nband)]).items():
-            out[b] = res[0]
+        out = _lib.result_empty(x.shape, np.float64)
+        for b in range(self.nband):
+            if b not in self.workers:
+                out[b] = 0.0
+        if self._hess_takes_out and x.ndim == 3:  # (nband, nx, ny): every band writes its (1, nx, ny) slice of the cube
+            self._map("hess_dot", [(x[b], out[b:b + 1]) for b in range(self.nband)])
+        else:
+            for b, res in self._map("hess_dot", [(x[b],) for b in range(self.nband)]).items():
+                out[b] = res[0]
         return self._exchange(out)
 
     def hess_cg(self, rhs, x0, tol, maxit, minit, verbosity):

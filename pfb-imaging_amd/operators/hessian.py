@@ -270,12 +270,15 @@ class HessianTree(object):
     def _slots(self, c):
         return [ip * self.ncorr + c for ip in range(len(self.parts))]
 
-    def dot(self, x):
+    def dot(self, x, out=None):
         xtmp = x if x.ndim == 3 else x[None, :, :]
         ncorr, nx, ny = xtmp.shape
         assert ncorr == self.ncorr, f"expected {self.ncorr} correlations on axis 0, got {ncorr}"
         assert nx == self.nx and ny == self.ny
-        out = np.zeros_like(xtmp, dtype=np.float64)
+        if out is None:
+            out = _lib.result_empty(xtmp.shape, np.float64)  # (every correlation's first partition overwrites its image)
+        elif out.shape != xtmp.shape or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of shape (ncorr, nx, ny)")
         for c in range(self.ncorr):
             scale = 1.0 / self.wsum[c]
             for k, s in enumerate(self._slots(c)):
