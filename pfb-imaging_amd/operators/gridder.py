@@ -17,7 +17,7 @@ from .. import _lib
 from .. import fft as _fft
 from ..misc import resize_thread_pool
 from ..utils.weighting import counts_to_weights, imaging_weights
-from ..wgridder import Gridder, dirty2vis, vis2dirty
+from ..wgridder import Gridder, _get_gridder, dirty2vis, vis2dirty
 
 lightspeed = 299792458.0
 ifftshift = np.fft.ifftshift
@@ -145,21 +145,24 @@ def grid_partition(part, counts, nx, ny, nx_psf, ny_psf, cell_rad, robustness=No
                   sigma_max=3.0)
     g = Gridder(uvw, freq, mask, npix_x=nx, npix_y=ny, **common)
     try:
-        dirty = np.zeros((ncorr, nx, ny), dtype=float)
+        dirty = _lib.result_empty((ncorr, nx, ny), np.float64)
         for c in range(ncorr):
-            dirty[c] = g.vis2dirty(vis[c], wgt[c])
+            g.vis2dirty(vis[c], wgt[c], out=dirty[c])
     finally:
         g.close()
 
     psf_vis = psf_visibilities(uvw, freq, x0, y0, flip_u, flip_v, dtype=np.complex128)
     g = Gridder(uvw, freq, mask, npix_x=nx_psf, npix_y=ny_psf, **common)
     try:
-        psf = np.zeros((ncorr, nx_psf, ny_psf), dtype=float)
+        psf = _lib.result_empty((ncorr, nx_psf, ny_psf), np.float64)
         for c in range(ncorr):
-            psf[c] = g.vis2dirty(psf_vis, wgt[c])
+            g.vis2dirty(psf_vis, wgt[c], out=psf[c])
     finally:
         g.close()
-    psfhat = _fft.r2c(ifftshift(psf, axes=(1, 2)), axes=(1, 2), nthreads=nthreads, forward=True, inorm=0)
+    if nx_psf % 2 == 0 and ny_psf % 2 == 0:  # (the shift as a checkerboard sign on the spectrum, on the device)
+        psfhat = _fft.r2c(psf, axes=(1, 2), nthreads=nthreads, forward=True, inorm=0, centred=True)
+    else:
+        psfhat = _fft.r2c(ifftshift(psf, axes=(1, 2)), axes=(1, 2), nthreads=nthreads, forward=True, inorm=0)
     return {"DIRTY": dirty, "PSF": psf, "PSFHAT": psfhat, "BEAM": beam, "WSUM": wsum, "WEIGHT": wgt}
 
 
@@ -255,9 +258,10 @@ def compute_residual_arrays(dirty, model, uvw, freq, wgt, mask, beam, cell_rad, 
     """The arithmetic of ``compute_residual`` (gridder.py:1060-1117) on in-memory arrays:
     per correlation ``dirty2vis(beam*model)`` -> ``vis2dirty`` -> ``dirty - convim``."""
     ncorr, nx, ny = dirty.shape
-    g = Gridder(uvw, freq, mask, npix_x=nx, npix_y=ny, pixsize_x=cell_rad, pixsize_y=cell_rad, center_x=x0,
-                center_y=y0, epsilon=epsilon, flip_u=flip_u, flip_v=flip_v, flip_w=flip_w, do_wgridding=do_wgridding,
-                divide_by_n=False, sigma_min=1.1, sigma_max=3.0)
+    # (the plan cache of the stateless calls: the reference computes the residual of the same uvw once per major cycle)
+    g, cached = _get_gridder(uvw, freq, mask, npix_x=int(nx), npix_y=int(ny), pixsize_x=float(cell_rad), pixsize_y=float(cell_rad),
+                             center_x=float(x0), center_y=float(y0), epsilon=float(epsilon), flip_u=bool(flip_u), flip_v=bool(flip_v),
+                             flip_w=bool(flip_w), do_wgridding=bool(do_wgridding), divide_by_n=False, sigma_min=1.1, sigma_max=3.0)
     devs = []
     try:
         # dirty - R^H W R (beam * model) in one device call per correlation: the beam is applied by the degridding side's
@@ -275,7 +279,8 @@ def compute_residual_arrays(dirty, model, uvw, freq, wgt, mask, beam, cell_rad, 
     finally:
         for d in devs:
             d.free()
-        g.close()
+        if not cached:
+            g.close()
     return residual
 
 
@@ -342,11 +347,16 @@ def image_data_products_arrays(uvw, freq, vis, wgt, mask, nx, ny, nx_psf, ny_psf
             products.update(WEIGHT=wgt, UVW=uvw, MASK=mask)
         wsum = wgt[:, mask.astype(bool)].sum(axis=-1)
         products["WSUM"] = wsum
+        # (every correlation's image comes down straight into its slice of a page-locked cube: no np.stack copy)
         if do_dirty:
-            products["DIRTY"] = np.stack([g.vis2dirty(vis[c], wgt[c]) for c in range(ncorr)])
+            products["DIRTY"] = _lib.result_empty((ncorr, nx, ny), np.float64)
+            for c in range(ncorr):
+                g.vis2dirty(vis[c], wgt[c], out=products["DIRTY"][c])
         if do_residual and model is not None:
             products["MODEL"] = np.asarray(model)
-            products["RESIDUAL"] = np.stack([g.vis2dirty(residual_vis[c], wgt[c]) for c in range(ncorr)])
+            products["RESIDUAL"] = _lib.result_empty((ncorr, nx, ny), np.float64)
+            for c in range(ncorr):
+                g.vis2dirty(residual_vis[c], wgt[c], out=products["RESIDUAL"][c])
         if do_noise:
             rng = np.random.default_rng() if rng is None else rng
             noise = np.empty((ncorr, nx, ny))
@@ -364,11 +374,17 @@ def image_data_products_arrays(uvw, freq, vis, wgt, mask, nx, ny, nx_psf, ny_psf
         psf_vis = psf_visibilities(uvw, freq, x0, y0, flip_u, flip_v, dtype=np.complex128)
         gp = Gridder(uvw, freq, mask, npix_x=nx_psf, npix_y=ny_psf, **common)
         try:
-            psf = np.stack([gp.vis2dirty(psf_vis, wgt[c]) for c in range(ncorr)])
+            psf = _lib.result_empty((ncorr, nx_psf, ny_psf), np.float64)
+            for c in range(ncorr):
+                gp.vis2dirty(psf_vis, wgt[c], out=psf[c])
         finally:
             gp.close()
         products["PSF"] = psf
-        products["PSFHAT"] = _fft.r2c(ifftshift(psf, axes=(1, 2)), axes=(1, 2), nthreads=nthreads, forward=True, inorm=0)
+        # r2c(ifftshift(psf)): for the even PSF sizes the shift is a checkerboard sign on the spectrum, applied on the device
+        if nx_psf % 2 == 0 and ny_psf % 2 == 0:
+            products["PSFHAT"] = _fft.r2c(psf, axes=(1, 2), nthreads=nthreads, forward=True, inorm=0, centred=True)
+        else:
+            products["PSFHAT"] = _fft.r2c(ifftshift(psf, axes=(1, 2)), axes=(1, 2), nthreads=nthreads, forward=True, inorm=0)
     if do_beam:
         products["BEAM"] = np.ones((ncorr, nx, ny)) if beam is None else np.asarray(beam)
     outputs = {"residual": products["RESIDUAL"] if (do_residual and model is not None) else products.get("DIRTY"),

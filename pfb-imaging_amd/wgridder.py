@@ -13,6 +13,7 @@ are cached, so the stateless calls inside a CG loop pay the set-up once.
 import collections
 import ctypes as ct
 import os
+import threading
 
 import numpy as np
 
@@ -111,8 +112,12 @@ class Gridder:
         return x
 
     # -- operators (host arrays) --------------------------------------------
-    def vis2dirty(self, vis, wgt=None):
-        if self._is_sp(vis, "c") and (wgt is None or self._is_sp(wgt, "r")):
+    def vis2dirty(self, vis, wgt=None, out=None):
+        """``out`` (double precision only: C-contiguous float64 of the image shape, e.g. one correlation of a caller's cube)
+        receives the image in place."""
+        if out is not None and (out.shape != (self.nx, self.ny) or out.dtype != np.float64 or not out.flags.c_contiguous):
+            raise ValueError("out must be a C-contiguous float64 array of the image shape")
+        if out is None and self._is_sp(vis, "c") and (wgt is None or self._is_sp(wgt, "r")):
             vis = as_c(vis, np.complex64)
             if vis.shape != (self.nrow, self.nchan):
                 raise ValueError(f"vis shape {vis.shape} != {(self.nrow, self.nchan)}")
@@ -120,7 +125,8 @@ class Gridder:
             check(lib().pfbhip_gridder_vis2dirty_sp(self._h, ptr(vis), ptr(self._sp_wgt(wgt)), ptr(out)))
             return out
         vis, wgt = self._vis(vis), self._wgt(wgt)
-        out = _lib.result_empty((self.nx, self.ny), np.float64)
+        if out is None:
+            out = _lib.result_empty((self.nx, self.ny), np.float64)
         check(lib().pfbhip_gridder_vis2dirty(self._h, ptr(vis), ptr(wgt), ptr(out)))
         return out
 
@@ -269,6 +275,7 @@ class Gridder:
 
 _CACHE_SIZE = int(os.environ.get("PFBHIP_PLAN_CACHE", "4"))
 _cache = collections.OrderedDict()
+_cache_lock = threading.Lock()  # (the map only: a plan evicted while another thread still runs on it is the caller's cache size to choose)
 
 
 def _fingerprint(a):
@@ -289,15 +296,23 @@ def _get_gridder(uvw, freq, mask, **kw):
     if _CACHE_SIZE <= 0:
         return Gridder(uvw, freq, mask, **kw), False
     key = (_fingerprint(uvw), _fingerprint(freq), _fingerprint(mask), tuple(sorted(kw.items())))
-    g = _cache.get(key)
-    if g is None:
-        g = Gridder(uvw, freq, mask, **kw)
-        _cache[key] = g
-        while len(_cache) > _CACHE_SIZE:
-            _, old = _cache.popitem(last=False)
-            old.close()
-    else:
-        _cache.move_to_end(key)
+    with _cache_lock:
+        g = _cache.get(key)
+        if g is not None:
+            _cache.move_to_end(key)
+            return g, True
+    g = Gridder(uvw, freq, mask, **kw)
+    evicted = []
+    with _cache_lock:
+        if key in _cache:  # (another thread planned the same inputs meanwhile: keep its plan)
+            evicted.append(g)
+            g = _cache[key]
+        else:
+            _cache[key] = g
+            while len(_cache) > _CACHE_SIZE:
+                evicted.append(_cache.popitem(last=False)[1])
+    for old in evicted:
+        old.close()
     return g, True
 
 
