@@ -56,7 +56,7 @@ def r2c(a, axes=(-2, -1), forward=True, inorm=0, out=None, nthreads=1, centred=F
     src = as_c(a if last_two else np.moveaxis(a, ax, (-2, -1)), np.float64)
     n0, n1 = src.shape[-2:]
     nbatch = int(np.prod(src.shape[:-2], dtype=np.int64))
-    res = np.empty(src.shape[:-2] + (n0, n1 // 2 + 1), dtype=np.complex128)
+    res = _lib.result_empty(src.shape[:-2] + (n0, n1 // 2 + 1), np.complex128)  # (page-locked: the download runs at the PCIe rate)
     fn = lib().pfbhip_r2c_2d_centred if centred else lib().pfbhip_r2c_2d
     check(fn(ptr(src), i64(nbatch), i64(n0), i64(n1), ptr(res)))
     if not forward:
@@ -91,7 +91,7 @@ def c2r(a, axes=(-2, -1), forward=False, lastsize=None, inorm=2, out=None, nthre
     if lastsize // 2 + 1 != nh:
         raise ValueError(f"lastsize={lastsize} is inconsistent with a half-complex axis of {nh}")
     nbatch = int(np.prod(src.shape[:-2], dtype=np.int64))
-    res = np.empty(src.shape[:-2] + (n0, int(lastsize)), dtype=np.float64)
+    res = _lib.result_empty(src.shape[:-2] + (n0, int(lastsize)), np.float64)
     check(lib().pfbhip_c2r_2d(ptr(src), i64(nbatch), i64(n0), i64(lastsize), ptr(res)))   # (scaled by 1 / N on the device)
     s = _norm(inorm, n0 * int(lastsize)) * float(n0 * int(lastsize))
     if abs(s - 1.0) > 1e-15:

@@ -118,8 +118,8 @@ class _BandWorkerImpl:
         from .psi import PsiBand
 
         self._psib = PsiBand(nx, ny, tuple(bases), nlevel)
-        self._alphao = np.empty((self._psib.nbasis, self._psib.nxmax, self._psib.nymax))
-        self._xo = np.empty((nx, ny))
+        self._alphao = _lib.result_empty((self._psib.nbasis, self._psib.nxmax, self._psib.nymax), np.float64)
+        self._xo = _lib.result_empty((nx, ny), np.float64)
         return int(self._psib.nxmax), int(self._psib.nymax)
 
     def psi_dot(self, x, out=None):

@@ -100,7 +100,7 @@ def hessian_psf_slice(x, xpad=None, xhat=None, xout=None, abspsf=None, beam=None
         bslot = 0
         plan.set_beam(0, beam)
     if xout is None:
-        xout = np.empty_like(x)
+        xout = _lib.result_empty(x.shape, np.float64)
     plan.apply(x, slot, beam_slot=bslot, eta=eta if eta else 0.0, out=xout)
     return xout
 
@@ -125,7 +125,7 @@ def hess_direct_slice(x, xpad=None, xhat=None, xout=None, abspsf=None, taperxy=N
     slot = cached_psf_slot(plan, abspsf)
     plan.set_beam(1, taperxy)
     if xout is None:
-        xout = np.empty_like(x)
+        xout = _lib.result_empty(x.shape, np.float64)
     plan.apply(x, slot, beam_slot=1, mode=1 if mode == "forward" else 2, shift=float(eta), out=xout)
     return xout
 
@@ -169,7 +169,7 @@ class HessPSF(object):
             self.set_beam(beam)
         else:
             self.beam = (None,) * self.nband
-        self.xout = np.empty((self.nband, self.nx, self.ny), dtype="f8")
+        self.xout = _lib.result_empty((self.nband, self.nx, self.ny), np.float64)  # (page-locked: downloads at the PCIe rate)
         self.cgtol = cgtol
         self.cgmaxit = cgmaxit
         self.cgverbose = cgverbose

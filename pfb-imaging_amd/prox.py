@@ -101,7 +101,7 @@ def prox_21m(v, sigma, weight=1.0, axis=0):
     nband = v.shape[0]
     n = v.size // max(nband, 1)
     w = as_c(np.broadcast_to(weight, v.shape[1:]), np.float64)
-    out = np.empty_like(v)
+    out = _lib.result_empty(v.shape, np.float64)
     check(lib().pfbhip_prox_21m(ptr(v), i64(nband), i64(n), f64(sigma), ptr(w), ptr(out)))
     return out
 

@@ -57,7 +57,7 @@ class PsfConv:
         if out is None:
             if accumulate:
                 raise ValueError("accumulate needs an output array")
-            out = np.empty_like(x)
+            out = _lib.result_empty(x.shape, np.float64)
         target = out if (out.flags.c_contiguous and out.dtype == np.float64) else np.array(out, dtype=np.float64)
         check(lib().pfbhip_psfconv_apply(self._h, ptr(x), i64(psf_slot), i64(beam_slot), cint(mode), f64(shift),
                                          f64(scale), f64(eta or 0.0), cint(int(accumulate)), ptr(target)))
@@ -70,7 +70,7 @@ class PsfConv:
         division of ``HessPSF.idot`` -- ``x /= beam**2`` where ``x > 0`` and ``beam > min_beam`` -- on the device.  ``raw`` (optional)
         receives the estimate before the division, ``out`` after it."""
         x = as_c(x, np.float64)
-        out = np.empty_like(x) if out is None else out
+        out = _lib.result_empty(x.shape, np.float64) if out is None else out
         assert out.flags.c_contiguous and out.dtype == np.float64 and (raw is None or (raw.flags.c_contiguous and raw.dtype == np.float64))
         check(lib().pfbhip_psfconv_direct(self._h, ptr(x), i64(psf_slot), i64(taper_slot), f64(shift), i64(beam_slot), f64(min_beam),
                                           ptr(raw), ptr(out)))

@@ -82,7 +82,7 @@ def box_sum_counts(counts, npix_super):
     _lib.require_gpu()
     c = as_c(counts, np.float64)
     ncorr, nx, ny = c.shape
-    out = np.empty_like(c)
+    out = _lib.result_empty(c.shape, np.float64)
     check(lib().pfbhip_box_sum_counts(ptr(c), i64(ncorr), i64(nx), i64(ny), i64(int(npix_super)), ptr(out)))
     return out.astype(counts.dtype, copy=False)
 
@@ -97,7 +97,7 @@ def imaging_weights(uvw, freq, mask, weight, nx_pad, ny_pad, cell_size_x, cell_s
     uvw, freq, mask = as_c(uvw, np.float64), as_c(freq, np.float64), as_c(mask, np.uint8)
     ncorr, nrow, nchan = weight.shape
     w = weight if (weight.flags.c_contiguous and weight.dtype == np.float64) else np.array(weight, dtype=np.float64)
-    counts = np.empty((ncorr, nx_pad, ny_pad), dtype=np.float64) if return_counts else None
+    counts = _lib.result_empty((ncorr, nx_pad, ny_pad), np.float64) if return_counts else None
     check(lib().pfbhip_imaging_weights(ptr(uvw), ptr(freq), ptr(mask), ptr(w), i64(ncorr), i64(nrow), i64(nchan), i64(nx_pad),
                                        i64(ny_pad), f64(cell_size_x), f64(cell_size_y), f64(usign), f64(vsign), f64(robust),
                                        f64(filter_level or 0.0), i64(int(npix_super or 0)), ptr(counts)))
