@@ -7,6 +7,7 @@
 #include "eskernel.hpp"
 
 #include <algorithm>
+#include <utility>
 #include <cmath>
 
 namespace pfbhip {
@@ -48,8 +49,13 @@ void gauss_legendre(int n, std::vector<double> &x, std::vector<double> &w)
 
 KernelFT::KernelFT(int W_, double beta_) : W(W_), beta(beta_)
 {
-    std::vector<double> gx, gw;
-    gauss_legendre(96, gx, gw);
+    // (the nodes are the same for every kernel row: the plan's row loop constructs ~200 of these)
+    static const std::pair<std::vector<double>, std::vector<double>> gl = [] {
+        std::pair<std::vector<double>, std::vector<double>> p;
+        gauss_legendre(96, p.first, p.second);
+        return p;
+    }();
+    const std::vector<double> &gx = gl.first, &gw = gl.second;
     s.resize(gx.size());
     pw.resize(gx.size());
     for (size_t i = 0; i < gx.size(); ++i) {
@@ -68,8 +74,14 @@ double KernelFT::operator()(double v) const
 
 std::vector<double> KernelFT::correction_1d(int64_t npix, int64_t ngrid) const
 {
+    // psi is even: one evaluation (96 cosines) per |i - npix / 2|
     std::vector<double> cf(npix);
-    for (int64_t i = 0; i < npix; ++i) cf[i] = 1.0 / (*this)(double(i - npix / 2) / double(ngrid));
+    const int64_t h = npix / 2;
+    for (int64_t k = 0; k <= h; ++k) {
+        const double v = 1.0 / (*this)(double(k) / double(ngrid));
+        if (h - k >= 0) cf[size_t(h - k)] = v;
+        if (h + k < npix) cf[size_t(h + k)] = v;
+    }
     return cf;
 }
 

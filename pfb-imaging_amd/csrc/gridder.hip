@@ -1812,7 +1812,8 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     // ---- correction image ----
     const int64_t npix = prm.nx * prm.ny;
     KernelFT ft(info.W, info.beta);
-    std::vector<double> cfu = ft.correction_1d(prm.nx, info.nu), cfv = ft.correction_1d(prm.ny, info.nv);
+    std::vector<double> cfu = ft.correction_1d(prm.nx, info.nu);
+    std::vector<double> cfv = (prm.ny == prm.nx && info.nv == info.nu) ? cfu : ft.correction_1d(prm.ny, info.nv);
     g->d_cfu.alloc(cfu.size());
     g->d_cfv.alloc(cfv.size());
     PFB_HIP(hipMemcpyAsync(g->d_cfu.p, cfu.data(), cfu.size() * sizeof(double), hipMemcpyHostToDevice, st));

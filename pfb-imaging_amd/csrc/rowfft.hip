@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -75,16 +77,30 @@ bool RowFFT::init(int64_t N)
     const long double pi = 3.141592653589793238462643383279502884L;
     // plain shapes: exp(-2 pi i k / N), k < N.  Doubled shapes: the N1-point table, then exp(-2 pi i k / N), k < N1.
     const int64_t n1 = pl.doubled ? N / 2 : N;
-    std::vector<double2> tw(static_cast<size_t>(pl.doubled ? 2 * n1 : n1), make_double2(0.0, 0.0));
-    for (int64_t k = 0; k < n1; ++k) {
-        long double a = -2.0L * pi * (long double)k / (long double)n1;
-        tw[size_t(k)] = make_double2(double(cosl(a)), double(sinl(a)));
+    // (host tables are kept per length: a plan has two axes, usually of one length, and a process builds many plans)
+    static std::mutex tw_mu;
+    static std::map<int64_t, std::vector<double2>> tw_cache;
+    std::vector<double2> tw;
+    {
+        std::lock_guard<std::mutex> lk(tw_mu);
+        auto it = tw_cache.find(N);
+        if (it != tw_cache.end()) tw = it->second;
     }
-    if (pl.doubled)
+    if (tw.empty()) {
+        tw.assign(static_cast<size_t>(pl.doubled ? 2 * n1 : n1), make_double2(0.0, 0.0));
         for (int64_t k = 0; k < n1; ++k) {
-            long double a = -2.0L * pi * (long double)k / (long double)N;
-            tw[size_t(n1 + k)] = make_double2(double(cosl(a)), double(sinl(a)));
+            long double a = -2.0L * pi * (long double)k / (long double)n1;
+            tw[size_t(k)] = make_double2(double(cosl(a)), double(sinl(a)));
         }
+        if (pl.doubled)
+            for (int64_t k = 0; k < n1; ++k) {
+                long double a = -2.0L * pi * (long double)k / (long double)N;
+                tw[size_t(n1 + k)] = make_double2(double(cosl(a)), double(sinl(a)));
+            }
+        std::lock_guard<std::mutex> lk(tw_mu);
+        if (tw_cache.size() >= 16) tw_cache.clear();
+        tw_cache[N] = tw;
+    }
     d_tw = static_cast<double2 *>(dev_alloc(tw.size() * sizeof(double2)));
     d_tw_bytes = tw.size() * sizeof(double2);
     PFB_HIP(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice));
