@@ -121,6 +121,8 @@ __global__ void k_keys(MapArgs m, uint32_t *keys, uint32_t *idx)
     if (m.key_sub > 1) {
         const uint32_t lu = uint32_t(wrap_index(p.iu0, m.nu)) % TILE, lv = uint32_t(wrap_index(p.iv0, m.nv)) % TILE;
         key = key * 64u + (lu >> 2) * 8u + (lv >> 2);
+        // 256: the 2 x 2-cell block inside the 4 x 4 one as well (4 x 4 runs stay contiguous: every block kernel can walk this order)
+        if (m.key_sub == 256) key = key * 4u + ((lu >> 1) & 1u) * 2u + ((lv >> 1) & 1u);
     }
     keys[i] = key;
 }
@@ -728,6 +730,7 @@ struct pfbhip_gridder {
     // one-plane w-scheme (info.wmode == 2, gridder_wd_api.hpp): K kernel functions per axis, their derivative tables, the K
     // complex coefficients of every sorted visibility; d_pval then holds K values per visibility
     WdArgs wd{};
+    int wd_bc = 4;  // block edge of the one-plane scatter's register frame (2: the sort key carries 2 x 2-cell blocks)
     DevBuf<double> d_dtab;
     DevBuf<double2> d_cw;
     bool wd_small = false;  // few work items: one scatter launch with the atomic tile flush instead of four colour launches
@@ -1506,6 +1509,14 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     const std::string smode = senv != nullptr ? std::string(senv) : std::string("auto");
     g->scatter_blk = smode != "walk";
     m.key_sub = (g->scatter_blk && nkeys * 64 < (int64_t(1) << 32) - 2) ? 64 : 1;
+    // one-plane scatter at W = 14 / 15: a 16 x 16-cell register frame anchored on 2 x 2-cell blocks (gridder_kernels_wd.hpp);
+    // PFBHIP_WD_BLOCK=4 keeps the 4 x 4 anchoring (18 x 18 frame on 3 x 20 lanes)
+    {
+        const char *benv = std::getenv("PFBHIP_WD_BLOCK");
+        const bool want2 = info.wmode == 2 && (info.W == 14 || info.W == 15) && !(benv != nullptr && benv[0] == '4');
+        if (m.key_sub == 64 && want2 && nkeys * 256 < (int64_t(1) << 32) - 2) m.key_sub = 256;
+    }
+    g->wd_bc = wd_block_edge(int(info.W), m.key_sub == 256);
     g->scatter_blk = m.key_sub > 1;  // without the block order in the 32-bit key the runs are ~1 long: the walk kernel is cheaper
     std::vector<WorkItem> work;
     uint32_t chunk_used = CHUNK;
@@ -1741,6 +1752,7 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
             wa = WdArgs{};
             wa.K = K;
             wa.W = W;
+            wa.bc = g->wd_bc;
             wa.whalf = info.whalf;
             wa.nshift = info.nshift;
             std::vector<double> dtab(size_t(K) * W * D1, 0.0);

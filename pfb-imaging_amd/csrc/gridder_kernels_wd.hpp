@@ -93,7 +93,19 @@ __host__ __device__ constexpr size_t wd_lds_doubles(int W, int waves)
     return size_t(2) * blk_tile_rows(W) * wd_stride(W) + size_t(waves) * WD_NLINE * WD_LINE + 64;  // (+ slack for the idle lanes' reads)
 }
 
-template <int W, int NJ>
+// Block edge BC (the anchor of the register footprint) and lane layout.  The frame a wave holds is FP = W + BC - 1 cells a side.
+//   FP <= 16 (round 4b): 16 columns x 4 row groups, rows 4 k + g, NR = ceil(FP / 4) <= 4 cells per lane -- every lane works, and
+//   W = 15 (C2) costs 4 x 2K cell FMAs per visibility instead of 6 x 2K.  W <= 13 fits with the 4 x 4-cell blocks of the tile sort;
+//   W = 14, 15 take 2 x 2-cell blocks (the sort key then carries the 2 x 2 block inside the 4 x 4 one: runs a quarter as long,
+//   flushes of 8 instead of 12 LDS atomics).
+//   FP > 16 (W = 16, or W = 14 / 15 when the finer sort key does not fit 32 bits): 20 columns x 3 row groups, rows 3 k + g.
+__host__ __device__ constexpr bool wd_frame16(int W, int BC) { return W + BC - 1 <= 16; }
+__host__ __device__ constexpr int wd_rows_per_lane(int W, int BC)
+{
+    return wd_frame16(W, BC) ? (W + BC - 1 + 3) / 4 : (W + BC - 1 + 2) / 3;
+}
+
+template <int W, int NJ, int BC>
 __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs wa, const VisRec *__restrict__ rec,
                                                            const double2 *__restrict__ pval, double2 *__restrict__ grid)
 {
@@ -102,10 +114,14 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
     constexpr int D2 = D - 4;  // degree of the round-2 chains (4th / 6th derivative)
     constexpr int LS = wd_stride(W);
     constexpr int LL = blk_tile_rows(W) * LS;
-    constexpr int FP = W + BLK_CELLS - 1;
-    constexpr int NR = blk_rows_per_lane(W);
-    constexpr int G = BLK_CELLS - 1;
-    constexpr bool SKIP = (FP % 3) == 1;
+    constexpr int FP = W + BC - 1;
+    constexpr bool F16 = wd_frame16(W, BC);
+    constexpr int NCOL = F16 ? 16 : 20, NGRP = F16 ? 4 : 3;
+    constexpr int NR = wd_rows_per_lane(W, BC);
+    constexpr int G = BC - 1;
+    constexpr bool SKIP = !F16 && (FP % 3) == 1;
+    static_assert(BC == 2 || BC == 4, "block edge: 2 or 4 cells");
+    static_assert(FP <= NCOL && NR * NGRP >= FP && G + 16 + G <= WD_ENT, "frame does not fit the lane layout");
     const int BLK_THREADS = int(blockDim.x);
     extern __shared__ double lds[];
     double *scr_all = lds + 2 * LL;
@@ -165,12 +181,12 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
     for (int i = threadIdx.x; i < (BLK_THREADS / 64) * WD_NLINE * WD_LINE; i += BLK_THREADS) scr_all[i] = 0.0;
 
     char *scr = reinterpret_cast<char *>(scr_all + wave * WD_NLINE * WD_LINE);
-    const int g = lane / 20, cc = lane - 20 * g;
-    const bool act = g < 3 && cc < FP;
+    const int g = lane / NCOL, cc = lane - NCOL * g;
+    const bool act = g < NGRP && cc < FP;
     // where this lane writes its kernel values: entry (b + G) of SU (even roles) / SV (odd roles), slot k
     char *wptr1 = scr + (((role & 1) ? WD_ENT : 0) + b + G) * 32 + (role >> 1) * 8;
     char *wptr2 = wptr1 + 16;
-    const char *suptr = scr + g * 32;               // + offu + 96 k: entry of row 3 k + g
+    const char *suptr = scr + g * 32;               // + offu + 32 NGRP k: entry of row NGRP k + g
     const char *svptr = scr + WD_ENT * 32 + cc * 32;  // + offv: entry of column cc
     __syncthreads();
 
@@ -183,14 +199,14 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
 
     char *const tile0 = reinterpret_cast<char *>(lds) + (g * LS + cc) * 8;
     auto flush = [&](int blk) {
-        const int r0 = (blk >> 8) * BLK_CELLS, c0 = (blk & 255) * BLK_CELLS;
+        const int r0 = (blk >> 8) * BC, c0 = (blk & 255) * BC;
         char *base = tile0 + (r0 * LS + c0) * 8;
         if (act) {
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
-                if (3 * k + g < FP) {
-                    unsafeAtomicAdd(reinterpret_cast<double *>(base + (3 * k * LS) * 8), are[k]);
-                    unsafeAtomicAdd(reinterpret_cast<double *>(base + (LL + 3 * k * LS) * 8), aim[k]);
+                if (NGRP * k + g < FP) {
+                    unsafeAtomicAdd(reinterpret_cast<double *>(base + (NGRP * k * LS) * 8), are[k]);
+                    unsafeAtomicAdd(reinterpret_cast<double *>(base + (LL + NGRP * k * LS) * 8), aim[k]);
                 }
             }
         }
@@ -250,7 +266,9 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
         for (int p = 0; p < NJ; ++p) asm volatile("" ::"s"(pq[u][p].x), "s"(pq[u][p].y));
     }
     zptr += 3 * 32;
-    if (nmine > 0) cur = kq[0].x;
+    // block of a visibility: the record's 4 x 4 block, or the 2 x 2 block of its first-tap cell (key = (lu << 8) | lv)
+    auto block_of = [](const int4 &r) { return BC == 4 ? r.x : ((r.w >> 1) & 0x0F0F); };
+    if (nmine > 0) cur = block_of(kq[0]);
     for (uint32_t wb = 0; wb < nmine; wb += 63) {
         asm volatile("" ::"v"(warm));
         warm = touch(j0 + wb + 63);
@@ -265,12 +283,13 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
                 zptr += 32;
 
                 const int4 rk = kq[u];
-                if (rk.x != cur) {
+                const int bnow = block_of(rk);
+                if (bnow != cur) {
                     flush(cur);
-                    cur = rk.x;
+                    cur = bnow;
                 }
                 // scratch offsets from the first-tap cell (rk.w = (lu << 8) | lv): entry G - du / G - dv
-                const int offu = (G - ((rk.w >> 8) & 3)) * 32, offv = (G - (rk.w & 3)) * 32;
+                const int offu = (G - ((rk.w >> 8) & (BC - 1))) * 32, offv = (G - (rk.w & (BC - 1))) * 32;
                 double B[NJ];
                 {
                     const char *sv = svptr + u * (WD_LINE * 8) + offv;
@@ -288,12 +307,12 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
                 double A[NR][NJ];
 #pragma unroll
                 for (int k = 0; k < NR; ++k) {
-                    const double2 a01 = *reinterpret_cast<const double2 *>(su + 96 * k);
+                    const double2 a01 = *reinterpret_cast<const double2 *>(su + 32 * NGRP * k);
                     A[k][0] = a01.x;
                     A[k][1] = a01.y;
-                    if constexpr (NJ == 3) A[k][2] = *reinterpret_cast<const double *>(su + 96 * k + 16);
+                    if constexpr (NJ == 3) A[k][2] = *reinterpret_cast<const double *>(su + 32 * NGRP * k + 16);
                     if constexpr (NJ == 4) {
-                        const double2 a23 = *reinterpret_cast<const double2 *>(su + 96 * k + 16);
+                        const double2 a23 = *reinterpret_cast<const double2 *>(su + 32 * NGRP * k + 16);
                         A[k][2] = a23.x;
                         A[k][3] = a23.y;
                     }

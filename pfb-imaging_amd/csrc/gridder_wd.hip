@@ -61,13 +61,22 @@ void wd_launch_plane_values(int K, int64_t nactive, const double2 *cw, const dou
     PFB_HIP(hipGetLastError());
 }
 
+template <int W, int NJ, int BC>
+static void grid_wkb(const GroupArgs &ga, const WdArgs &wa, const VisRec *rec, const double2 *pval, double2 *grid, hipStream_t st)
+{
+    allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_wd<W, NJ, BC>), 160 * 1024);
+    const int threads = scatter_threads_for(ga.a.nwork);
+    const size_t lds = wd_lds_doubles(W, threads / 64) * sizeof(double);
+    hipLaunchKernelGGL((k_grid_wd<W, NJ, BC>), dim3(ga.a.nwork), dim3(threads), lds, st, ga, wa, rec, pval, grid);
+}
 template <int W, int NJ>
 static void grid_wk(const GroupArgs &ga, const WdArgs &wa, const VisRec *rec, const double2 *pval, double2 *grid, hipStream_t st)
 {
-    allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_wd<W, NJ>), 160 * 1024);
-    const int threads = scatter_threads_for(ga.a.nwork);
-    const size_t lds = wd_lds_doubles(W, threads / 64) * sizeof(double);
-    hipLaunchKernelGGL((k_grid_wd<W, NJ>), dim3(ga.a.nwork), dim3(threads), lds, st, ga, wa, rec, pval, grid);
+    if constexpr (W == 14 || W == 15) {
+        if (wa.bc == 2) return grid_wkb<W, NJ, 2>(ga, wa, rec, pval, grid, st);
+    }
+    if (wa.bc != 4) throw std::runtime_error("one-plane scatter: block edge 2 is built for W = 14, 15 only");
+    grid_wkb<W, NJ, 4>(ga, wa, rec, pval, grid, st);
 }
 template <int W>
 static void grid_w(const GroupArgs &ga, const WdArgs &wa, const VisRec *rec, const double2 *pval, double2 *grid, hipStream_t st)

@@ -10,6 +10,7 @@ constexpr int WD_MAX_K = 4;
 struct WdArgs {
     int K;                      // kernel functions per axis (2..4)
     int W;
+    int bc;                     // block edge of the scatter's register frame: 4, or 2 when the sort key carries 2 x 2-cell blocks (W = 14, 15)
     double whalf, nshift;
     double tq[WD_MAX_K];        // t(s_q) = n(s_q) - 1 + nshift at the K interpolation nodes in s
     double M[WD_MAX_K][WD_MAX_K];  // C_k = sum_q M[k][q] exp(-2 pi i dw t_q)
@@ -18,6 +19,8 @@ struct WdArgs {
     const double2 *cw;          // (nactive + REC_PAD, K): C_k of every sorted visibility (gridding direction)
 };
 
+// the block edge the scatter of a plan of support W runs with, given whether its sort key carries 2 x 2-cell blocks
+__host__ __device__ constexpr int wd_block_edge(int W, bool fine_key) { return (W == 14 || W == 15) && fine_key ? 2 : BLK_CELLS; }
 // threads per workgroup of the scatter (the caller sizes the dynamic LDS with wd_scatter_lds_bytes)
 int wd_scatter_threads();
 size_t wd_scatter_lds_bytes(int W);

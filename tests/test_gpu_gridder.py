@@ -821,6 +821,38 @@ def test_one_plane_work_item_sizes(env, monkeypatch):
     assert rel(d1, d0) < 1e-10 and rel(v1, v0) < 1e-10 and rel(h1, h0) < 1e-10
 
 
+@pytest.mark.parametrize("W, sigma", [(13, 1.5), (14, 1.4), (15, 1.3), (16, 1.25)])
+@pytest.mark.parametrize("colours", ["0", "1"])
+def test_one_plane_scatter_frames(W, sigma, colours, monkeypatch):
+    """The one-plane scatter's register frame (csrc/gridder_kernels_wd.hpp): 16 x 16 cells on 4 x 16 lanes for W <= 15 -- anchored on the
+    4 x 4-cell blocks of the tile sort up to W = 13, on 2 x 2-cell blocks (finer sort key) for W = 14, 15 --, 3 x 20 lanes for W = 16 and
+    under PFBHIP_WD_BLOCK=4.  Every form against the CPU restatement run with the plan's parameters (1e-10), against the direct DFT
+    (epsilon), and the two anchorings of one plan against each other (summation order only)."""
+    c = synth.make_case(60000, 2, 512, zscale=1e-3, seed=11)
+    cell = c["cell"] * 16.0
+    monkeypatch.setenv("PFBHIP_WD_COLOURS", colours)
+    pix = (np.arange(0, 512 * 512, 41) // 512, np.arange(0, 512 * 512, 41) % 512)
+    ref = dft.dft_vis2dirty(c["uvw"], c["freq"], c["vis"], c["wgt"], c["mask"], 512, 512, cell, cell, 0, 0, False, True, False, True, False,
+                            pixels=pix)
+
+    def run():
+        g, kw, mask = gpu_plan(c, npix_x=512, npix_y=512, pixsize_x=cell, pixsize_y=cell, epsilon=1e-7, force_wmode=2, force=(sigma, W))
+        assert g.info["wmode"] == 2 and g.info["W"] == W, g.info
+        o = oracle_plan(c, g, kw, mask)
+        d = g.vis2dirty(c["vis"], c["wgt"])
+        assert rel(d, o.vis2dirty(c["vis"], c["wgt"])) < 1e-10
+        assert rel(d[pix], ref) < 1e-7
+        g.set_weights(c["wgt"])
+        h = g.hessian(np.ascontiguousarray(c["x"]), eta=0.1, wsum=3.0)
+        g.close()
+        return d, h
+
+    d0, h0 = run()
+    monkeypatch.setenv("PFBHIP_WD_BLOCK", "4")
+    d1, h1 = run()
+    assert rel(d1, d0) < 1e-10 and rel(h1, h0) < 1e-10
+
+
 def test_apply_graph_replay(monkeypatch):
     """PFBHIP_GRAPH=1: the Hessian apply replayed from a captured hipGraph (csrc/gridder.hip: hessian_dev_impl): the first call with
     a set of buffers runs eagerly, the second captures, later ones replay -- with new contents of x, new weights, and in the
