@@ -389,17 +389,18 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
 // Gather: k_degrid_rw's row walk (lane b on footprint column (b - lv) mod 16, the u-kernel value broadcast from the lane that
 // evaluated it by v_fmac_f64_dpp row_newbcast) on ONE tile, with K u-kernel functions: T_r(col) = sum_i a_r(i) cell(i, col),
 // then value = sum_col sum_r T_r(col) conj(S_r(col)), S_r from the C_k of the visibility (see the header comment).
-template <int NJ, int I>
+// (rows I >= W carry zero kernel values -- the lanes b >= W hold zero coefficients --: the walk stops at W)
+template <int W, int NJ, int I>
 __device__ __forceinline__ void wd_steps(const char *base, const double (&ku)[NJ], double (&tr)[NJ], double (&ti)[NJ])
 {
-    if constexpr (I < 16) {
+    if constexpr (I < W) {
         const double2 cell = *reinterpret_cast<const double2 *>(base + size_t(I) * RW_LS * 16);
 #pragma unroll
         for (int r = 0; r < NJ; ++r) {
             fmac_row_bcast<I>(tr[r], ku[r], cell.x);
             fmac_row_bcast<I>(ti[r], ku[r], cell.y);
         }
-        wd_steps<NJ, I + 1>(base, ku, tr, ti);
+        wd_steps<W, NJ, I + 1>(base, ku, tr, ti);
     }
 }
 
@@ -522,7 +523,7 @@ __global__ void __launch_bounds__(wd_gather_threads(NJ)) k_degrid_wd(GroupArgs g
             for (int r = 0; r < NJ; ++r) tr[r] = ti[r] = 0.0;
 #pragma unroll
             for (int r = 0; r < NJ; ++r) asm volatile("s_nop 1" : "+v"(ku[r]));  // VALU write -> DPP read needs 2 wait states
-            wd_steps<NJ, 0>(base, ku, tr, ti);
+            wd_steps<W, NJ, 0>(base, ku, tr, ti);
             // Q_r = conj(S_r), S_r = sum_m binom(r + m, r) C_{r+m} b_m ; value += T_r Q_r
             double vr = 0.0, vi = 0.0;
 #pragma unroll
