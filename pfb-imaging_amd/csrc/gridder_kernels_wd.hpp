@@ -80,8 +80,9 @@ __global__ void k_plane_values_wd(int K, int64_t nactive, const double2 *__restr
 //   the other two's visibility loops.  (384 threads x 2 was SLOWER than 768 x 1: six waves do not spread evenly over four
 //   SIMDs, and at 3 waves per SIMD by registers the second workgroup does not fit beside the first.)  The LDS budget of three
 //   workgroups is what sets the tile stride (the region's edge rounded up to odd) and the 22-entry scratch arrays.
-//   kernel evaluation: round 1 -- lanes 0..15 a_0, 16..31 b_0, 32..47 a_1, 48..63 b_1 (degree D); round 2 (K >= 3) -- a_2, b_2,
-//   a_3, b_3 (degree D - 4), each lane one Horner chain on its own coefficient registers.
+//   kernel evaluation (round 4b): for a PAIR of visibilities at a time -- lanes 0..15 u / 16..31 v of the first, 32..47 u / 48..63 v of the
+//   second; lane (axis, tap) runs the K Horner chains (degrees D, D - 2, D - 4 [, D - 6]) on its own coefficient registers and writes
+//   its whole scratch entry.  Visibility s lives in line s mod 3; the pair (s + 1, s + 2) is evaluated under every second visibility.
 constexpr int WD_ENT = 22;               // entries per scratch array: G + 16 taps + G
 constexpr int WD_LINE = 2 * WD_ENT * 4;  // doubles per scratch line
 constexpr int WD_NLINE = 3;
@@ -111,7 +112,6 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
 {
     const PlaneArgs &a = ga.a;
     constexpr int D = kernel_poly_degree_c(W);
-    constexpr int D2 = D - 4;  // degree of the round-2 chains (4th / 6th derivative)
     constexpr int LS = wd_stride(W);
     constexpr int LL = blk_tile_rows(W) * LS;
     constexpr int FP = W + BC - 1;
@@ -150,22 +150,43 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
     constexpr uint32_t pbytes = uint32_t(NJ) * 16u;
     const char *rbase = reinterpret_cast<const char *>(rec);
     const char *pbase = reinterpret_cast<const char *>(pval);
-    const int role = lane >> 4, b = lane & 15;  // role: 0 u / k = 0, 1 v / k = 0, 2 u / k = 1, 3 v / k = 1 (round 2: k + 2)
-    const char *zptr = rbase + size_t(j0) * 32 + ((role & 1) ? 8 : 0);
-    // per-lane coefficient registers, scaled by (-alpha / smax)^k of the lane's axis
-    double c1[D + 1], c2[D2 + 1];
-    {
+    // Kernel evaluation.  PAIR (round 4b; the 16 x 16 frame with K <= 3, where the registers allow it): for TWO visibilities at a time --
+    // lanes 0..15 u / 16..31 v of the pair's first visibility, 32..47 u / 48..63 v of its second; lane (axis, b) runs the NJ Horner
+    // chains of tap b on its own coefficient registers (scaled by (-alpha / smax)^k of the lane's axis): 3 D - 5 instructions per pair
+    // at NJ = 3, every lane busy.  Otherwise one visibility at a time: round 1 -- lanes 0..15 a_0, 16..31 b_0, 32..47 a_1, 48..63 b_1
+    // (degree D), round 2 (K >= 3) -- a_2, b_2, a_3, b_3 (degree D - 4): 2 D - 2 instructions per visibility.
+    constexpr bool PAIR = F16 && NJ <= 3;
+    constexpr int D2 = D - 4;
+    const int role = lane >> 4, b = lane & 15;
+    const int axis = role & 1, vsel = role >> 1;
+    // z of the lane's axis: PAIR -- of visibility j0 + vsel, + 2 per pair; else of visibility j0, + 1 per visibility
+    const char *zptr = rbase + (size_t(j0) + size_t(PAIR ? vsel : 0)) * 32 + (axis ? 8 : 0);
+    double cA[PAIR ? D + 1 : 1], cB[PAIR ? D - 1 : 1], cC[PAIR && NJ > 2 ? D - 3 : 1];
+    double c1[PAIR ? 1 : D + 1], c2[PAIR ? 1 : D2 + 1];
+    if constexpr (PAIR) {
+        const bool on = b < W;
+        const double s0 = axis ? wa.sv[0] : wa.su[0], s1 = axis ? wa.sv[1] : wa.su[1];
+#pragma unroll
+        for (int q = 0; q <= D; ++q) cA[q] = on ? wa.dtab[(size_t(0) * W + b) * (D + 1) + q] * s0 : 0.0;
+#pragma unroll
+        for (int q = 0; q <= D - 2; ++q) cB[q] = on ? wa.dtab[(size_t(1) * W + b) * (D + 1) + q] * s1 : 0.0;
+        if constexpr (NJ > 2) {
+            const double s2 = axis ? wa.sv[2] : wa.su[2];
+#pragma unroll
+            for (int q = 0; q <= D - 4; ++q) cC[q] = on ? wa.dtab[(size_t(2) * W + b) * (D + 1) + q] * s2 : 0.0;
+        }
+    } else {
         const int k1 = role >> 1, k2 = 2 + (role >> 1);
-        const double s1 = (role & 1) ? wa.sv[k1] : wa.su[k1];
+        const double s1 = axis ? wa.sv[k1] : wa.su[k1];
         const bool on1 = b < W && k1 < NJ;
 #pragma unroll
         for (int q = 0; q <= D; ++q) c1[q] = on1 ? wa.dtab[(size_t(k1) * W + b) * (D + 1) + q] * s1 : 0.0;
         const bool on2 = b < W && k2 < NJ;
-        const double s2 = on2 ? ((role & 1) ? wa.sv[k2] : wa.su[k2]) : 0.0;
+        const double s2 = on2 ? (axis ? wa.sv[k2] : wa.su[k2]) : 0.0;
 #pragma unroll
         for (int q = 0; q <= D2; ++q) c2[q] = on2 ? wa.dtab[(size_t(k2 < NJ ? k2 : 0) * W + b) * (D + 1) + q] * s2 : 0.0;
     }
-    static_assert(REC_PAD >= 63 + 63 + 3, "the warm-up reads one entry per lane up to 63 + 63 past the current visibility");
+    static_assert(REC_PAD >= 63 + 63 + 3, "the warm-up reads one entry per lane up to 63 + 63 past the current visibility (z: at most five pairs ahead)");
     auto touch = [&](uint32_t first) {
         const uint32_t jt = first + uint32_t(lane);  // (padded arrays: no clamp)
         const int t0 = *reinterpret_cast<const int *>(rbase + size_t(jt) * 32 + 16);
@@ -173,9 +194,11 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
         return double(t0) + t1;
     };
     double warm = touch(j0);
-    double zq[3];
+    constexpr int ZSTEP = PAIR ? 64 : 32;
+    double zq[3];  // z of the lane's axis for the next three pairs (slot = pair index mod 3) / visibilities
 #pragma unroll
-    for (int u = 0; u < 3; ++u) zq[u] = *reinterpret_cast<const double *>(zptr + u * 32);
+    for (int u = 0; u < 3; ++u) zq[u] = *reinterpret_cast<const double *>(zptr + u * ZSTEP);
+    zptr += 3 * ZSTEP;
 
     for (int i = threadIdx.x; i < 2 * LL; i += BLK_THREADS) lds[i] = 0.0;
     for (int i = threadIdx.x; i < (BLK_THREADS / 64) * WD_NLINE * WD_LINE; i += BLK_THREADS) scr_all[i] = 0.0;
@@ -183,9 +206,16 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
     char *scr = reinterpret_cast<char *>(scr_all + wave * WD_NLINE * WD_LINE);
     const int g = lane / NCOL, cc = lane - NCOL * g;
     const bool act = g < NGRP && cc < FP;
-    // where this lane writes its kernel values: entry (b + G) of SU (even roles) / SV (odd roles), slot k
-    char *wptr1 = scr + (((role & 1) ? WD_ENT : 0) + b + G) * 32 + (role >> 1) * 8;
-    char *wptr2 = wptr1 + 16;
+    // where this lane writes its kernel values: entry (b + G) of SU (u lanes) / SV (v lanes) -- the whole entry (a_0 .. a_{NJ-1}) --
+    // of the line of ITS visibility.  Visibility s lives in line s mod 3; the pair (s + 1, s + 2) is evaluated while visibility s
+    // (s odd within a block of six) is processed: wq[q] for s = 2 q + 1.
+    char *const went = scr + ((axis ? WD_ENT : 0) + b + G) * 32;
+    char *wq[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) wq[q] = went + ((2 * q + 2 + vsel) % 3) * (WD_LINE * 8);
+    // (one visibility at a time: slot k = role >> 1 of the entry in round 1, k + 2 in round 2)
+    char *const wptr1 = went + (role >> 1) * 8;
+    char *const wptr2 = wptr1 + 16;
     const char *suptr = scr + g * 32;               // + offu + 32 NGRP k: entry of row NGRP k + g
     const char *svptr = scr + WD_ENT * 32 + cc * 32;  // + offv: entry of column cc
     __syncthreads();
@@ -214,34 +244,44 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
         for (int k = 0; k < NR; ++k) are[k] = aim[k] = 0.0;
     };
 
-    // two independent half chains (even / odd powers): a single wave can issue them back to back
-    auto chain1 = [&](double z) {
-        const double z2 = z * z;
-        double e = c1[D], o = c1[D - 1];
+    // Horner in z^2 on the even / odd coefficients (two independent half chains: a single wave can issue them back to back)
+    auto evens = [](const auto &c, auto deg, double zz, double z2) {
+        constexpr int DG = decltype(deg)::value;
+        double e = c[DG], o = c[DG - 1];
 #pragma unroll
-        for (int k = D - 2; k >= 0; k -= 2) {
-            e = fma(e, z2, c1[k]);
-            if (k >= 1) o = fma(o, z2, c1[k - 1]);
+        for (int k = DG - 2; k >= 0; k -= 2) {
+            e = fma(e, z2, c[k]);
+            if (k >= 1) o = fma(o, z2, c[k - 1]);
         }
-        return fma(o, z, e);
+        return fma(o, zz, e);
     };
-    auto chain2 = [&](double z) {
-        const double z2 = z * z;
-        double e = c2[D2], o = c2[D2 - 1];
-#pragma unroll
-        for (int k = D2 - 2; k >= 0; k -= 2) {
-            e = fma(e, z2, c2[k]);
-            if (k >= 1) o = fma(o, z2, c2[k - 1]);
+    static_assert((D & 1) == 0 && D >= 8, "even polynomial degrees assumed");
+    auto eval_pair = [&](double z, char *wp) {
+        if constexpr (PAIR) {
+            const double z2 = z * z;
+            const double f0 = evens(cA, std::integral_constant<int, D>{}, z, z2);
+            const double f1 = evens(cB, std::integral_constant<int, D - 2>{}, z, z2);
+            *reinterpret_cast<double2 *>(wp) = make_double2(f0, f1);
+            if constexpr (NJ == 3) *reinterpret_cast<double *>(wp + 16) = evens(cC, std::integral_constant<int, D - 4>{}, z, z2);
         }
-        return fma(o, z, e);
     };
-    static_assert((D & 1) == 0 && (D2 & 1) == 0, "even polynomial degrees assumed");
     auto stage_a = [&](double z, int line) {
-        *reinterpret_cast<double *>(wptr1 + line * (WD_LINE * 8)) = chain1(z);
-        if constexpr (NJ > 2) *reinterpret_cast<double *>(wptr2 + line * (WD_LINE * 8)) = chain2(z);
+        if constexpr (!PAIR) {
+            const double z2 = z * z;
+            *reinterpret_cast<double *>(wptr1 + line * (WD_LINE * 8)) = evens(c1, std::integral_constant<int, D>{}, z, z2);
+            if constexpr (NJ > 2)
+                *reinterpret_cast<double *>(wptr2 + line * (WD_LINE * 8)) = evens(c2, std::integral_constant<int, D2>{}, z, z2);
+        }
     };
     const unsigned long long ts1 = stamp ? __builtin_readcyclecounter() : 0ull;
-    if (nmine > 0) stage_a(zq[0], 0);
+    if (nmine > 0) {
+        if constexpr (PAIR) {  // pair 0 -> lines 0, 1
+            eval_pair(zq[0], wq[2]);
+            zq[0] = *reinterpret_cast<const double *>(zptr);
+            zptr += ZSTEP;
+        } else
+            stage_a(zq[0], 0);
+    }
     int cur = -1;
     int4 kq[3];
     double2 pq[3][NJ];
@@ -265,23 +305,25 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
 #pragma unroll
         for (int p = 0; p < NJ; ++p) asm volatile("" ::"s"(pq[u][p].x), "s"(pq[u][p].y));
     }
-    zptr += 3 * 32;
     // block of a visibility: the record's 4 x 4 block, or the 2 x 2 block of its first-tap cell (key = (lu << 8) | lv)
     auto block_of = [](const int4 &r) { return BC == 4 ? r.x : ((r.w >> 1) & 0x0F0F); };
     if (nmine > 0) cur = block_of(kq[0]);
-    for (uint32_t wb = 0; wb < nmine; wb += 63) {
+    constexpr uint32_t BS = PAIR ? 6u : 3u, WS = PAIR ? 60u : 63u;  // unrolled block (visibility s: line s mod 3, pair s / 2), warm-up stride
+    for (uint32_t wb = 0; wb < nmine; wb += WS) {
         asm volatile("" ::"v"(warm));
-        warm = touch(j0 + wb + 63);
-        const uint32_t wend = min(wb + 63u, nmine);
-        for (uint32_t sb = wb; sb < wend; sb += 3) {
+        warm = touch(j0 + wb + WS);
+        const uint32_t wend = min(wb + WS, nmine);
+        for (uint32_t sb = wb; sb < wend; sb += BS) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                if (sb + uint32_t(u) >= wend) break;
-                const int ld = (u + 2) % 3, nx = (u + 1) % 3;
-                const double znext = zq[nx];
-                zq[u] = *reinterpret_cast<const double *>(zptr);
-                zptr += 32;
-
+            for (int i6 = 0; i6 < int(BS); ++i6) {
+                if (sb + uint32_t(i6) >= wend) break;
+                const int u = i6 % 3, ld = (u + 2) % 3, nx = (u + 1) % 3;
+                double znext = 0.0;
+                if constexpr (!PAIR) {
+                    znext = zq[nx];
+                    zq[u] = *reinterpret_cast<const double *>(zptr);
+                    zptr += ZSTEP;
+                }
                 const int4 rk = kq[u];
                 const int bnow = block_of(rk);
                 if (bnow != cur) {
@@ -317,7 +359,15 @@ __global__ void __launch_bounds__(wd_threads()) k_grid_wd(GroupArgs ga, WdArgs w
                         A[k][3] = a23.y;
                     }
                 }
-                stage_a(znext, nx);  // kernel values of visibility s + 1 -> line nx
+                if constexpr (PAIR) {
+                    if (i6 & 1) {  // kernel values of the pair (s + 1, s + 2) -> their lines
+                        const int q = i6 >> 1, slot = (q + 1) % 3;
+                        eval_pair(zq[slot], wq[q]);
+                        zq[slot] = *reinterpret_cast<const double *>(zptr);
+                        zptr += ZSTEP;
+                    }
+                } else
+                    stage_a(znext, nx);  // kernel values of visibility s + 1 -> line nx
 #pragma unroll
                 for (int k = 0; k < NR; ++k)
 #pragma unroll
