@@ -432,13 +432,19 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
         pmc, pmc_file = {}, None
         import glob
 
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=os.path.getmtime)  # newest by time
-        if cands:
+        # the newest tracked profile: by the collection time written into the file (mtimes do not survive a checkout)
+        best = None
+        for fn in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")):
             try:
-                pmc = json.load(open(cands[-1]))
-                pmc_file = os.path.relpath(cands[-1], ROOT) + " (separate rocprofv3 --pmc passes of this command)"
+                cand = json.load(open(fn))
             except Exception:
-                pmc = {}
+                continue
+            stamp = (float(cand.get("_collected_unix", 0.0)), os.path.basename(fn))
+            if best is None or stamp > best[0]:
+                best = (stamp, fn, cand)
+        if best is not None:
+            pmc = best[2]
+            pmc_file = os.path.relpath(best[1], ROOT) + " (separate rocprofv3 --pmc passes of this command)"
         names = dict(KERNEL_OF)
         if info["wmode"] == 2:
             names.update({"grid": "k_grid_wd", "degrid": "k_degrid_wd"})
@@ -448,7 +454,8 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
             names["grid"] = "k_grid_blk" if info["scatter_mode"] == 1 else "k_grid_mp"
         if not info["fft_mode"] & 8:
             names["fft_rows"] = "k_rowfft_plain"
-        scatter_txt = {2: (f"record-driven register footprint, {info['nderiv']} kernel functions per axis (k_grid_wd), " if info["wmode"] == 2 else
+        scatter_txt = {2: (f"record-driven register footprint ({info['W'] + info.get('scatter_block', 4) - 1}-cell frame on {info.get('scatter_block', 4)} x {info.get('scatter_block', 4)}-cell blocks), "
+                           f"{info['nderiv']} kernel functions per axis (k_grid_wd), " if info["wmode"] == 2 else
                            "record-driven register footprint (k_grid_rec), ") + f"{info['scatter_launches']} launch(es) per pass",
                        1: f"register footprint (k_grid_blk), {info['scatter_launches']} launch(es) per pass",
                        0: "diagonal walk (k_grid_mp)"}[info["scatter_mode"]]
@@ -526,10 +533,16 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
             if info["scatter_mode"] == 2 and (info["W"] + 3) % 3 == 1:
                 nr -= 1
             if info["wmode"] == 2:
-                # K complex FMAs per held cell, the K column sums S_r (K (K + 1) real operations + the binomial multiples),
-                # two rounds of kernel polynomials (degree 12, and 8 for the fourth / sixth derivatives)
+                # K complex FMAs per held cell, the K column sums S_r (K (K + 1) real operations + the binomial multiples), and the
+                # kernel polynomials: a 16 x 16-cell frame on 4 x 16 lanes (W + block edge - 1 <= 16: 4 cells per lane) with the K
+                # Horner chains of degree 12, 10, 8 run for two visibilities at a time (K <= 3); else 3 x 20 lanes and two rounds per
+                # visibility (degree 12, and 8 for the fourth / sixth derivatives)
                 K = info["nderiv"]
-                f64_ops = nr * 2 * K + (K * (K + 1) + K - 2) + 14 + (9 if K > 2 else 0)
+                frame = info["W"] + info.get("scatter_block", 4) - 1
+                if frame <= 16:
+                    nr = -(-frame // 4)
+                horner = (sum(12 - 2 * k for k in range(K)) + 1) / 2 if (frame <= 16 and K <= 3) else 14 + (9 if K > 2 else 0)
+                f64_ops = nr * 2 * K + (K * (K + 1) + K - 2) + horner
             else:
                 f64_ops = nr * (1 + 2 * kp) + 14
             nsl = max(int(info["scatter_launches"]), 1)
@@ -538,7 +551,7 @@ def bench_gridder(args, comm, use_rccl, rccl_error, synth, Gridder, DeviceArray,
             # The stage is bound by f64 VALU issue, not by HBM.  Headline figures of the object (count what is
             # USEFUL, not what is issued): achieved = the footprint's multiply-adds only -- W^2 cells x (K kernel functions, or the
             # planes a visibility touches) x (re, im) x 2 flop per visibility; kernel evaluation, the column sums and the zero cells of
-            # the 19 x 21 lane frame are not counted -- / the launch time, against the f64 peak (vector and matrix: the same
+            # the lane frame are not counted -- / the launch time, against the f64 peak (vector and matrix: the same
             # 78.6 TFLOP/s on this part; the kernel issues v_fma_f64).  What the kernel must ISSUE, padding included, is in
             # `limiter`; the HBM figures the contract defines are in `hbm`.
             r = out["roofline"]

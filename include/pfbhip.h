@@ -146,6 +146,10 @@ typedef struct pfbhip_gridder_info {
     /* Hessian applies replayed from a captured hipGraph so far (opt-in: PFBHIP_GRAPH=1; measured at parity with eager
      * launches even at C1's size, see gridder.hip) */
     int64_t graph_replays;
+    /* edge (cells) of the blocks the register-footprint scatters anchor their frame on: 4 (the tile sort's 4 x 4-cell blocks), or 2
+     * for the one-plane scatter at W = 14, 15 (16 x 16-cell frame on 4 x 16 lanes; the sort key then carries the 2 x 2 block) */
+    int32_t scatter_block;
+    int32_t reserved0;
 } pfbhip_gridder_info;
 
 int pfbhip_gridder_create(const pfbhip_gridder_params *params, const double *uvw_host /* (nrow,3) */,

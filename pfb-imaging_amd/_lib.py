@@ -41,6 +41,7 @@ class GridderInfo(ct.Structure):
         ("wmode", i32), ("occ_rows", i32), ("wcenter", f64), ("whalf", f64), ("device_bytes", ct.c_size_t),
         ("fft_mode", i32), ("screen_poly", i32), ("scatter_mode", i32), ("scatter_launches", i32),
         ("used_cells", i64), ("screen_composite", i32), ("screen_separable", i32), ("nderiv", i32), ("smax", f64), ("graph_replays", i64),
+        ("scatter_block", i32), ("reserved0", i32),
     ]
 
     def asdict(self):

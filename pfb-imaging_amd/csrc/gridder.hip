@@ -2247,6 +2247,8 @@ int pfbhip_gridder_get_info(const pfbhip_gridder *g, pfbhip_gridder_info *info)
         std::swap(info->lshift, info->mshift);
         info->device_bytes = g->device_bytes();
         info->graph_replays = g->graph_replays;
+        info->scatter_block = g->wd_bc;
+        info->reserved0 = 0;
     });
 }
 

@@ -51,6 +51,12 @@ def main():
     out["_kernels"] = bench.get("roofline", {}).get("stage_kernels", {})  # the kernel each stage timer bracketed in that run
     out["_note"] = ("HBM bytes per stage launch = (2*FETCH_SIZE + WRITE_SIZE) KiB / (stage launches per apply x applies), "
                     "rocprofv3 --pmc in two separate passes; gfx950 FETCH_SIZE x2 correction applied (upper bound)")
+    import subprocess, time
+    out["_collected_unix"] = int(time.time())  # bench.py picks the newest profile by this (mtimes do not survive a checkout)
+    try:
+        out["_collected_at_commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        out["_collected_at_commit"] = None
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
