@@ -713,13 +713,22 @@ struct pfbhip_gridder {
     {
         return (size_t(2) * KP * blk_tile_rows(W) * blk_stride(W, KP) + blk_fixed_doubles(W, blk_threads(kp_max) / 64)) * sizeof(double);
     }
+    template <int W, int KP, int BC>
+    void launch_grid_blk_wkb(const GroupArgs &ga, const double2 *sval)
+    {
+        allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_blk<W, KP, BC>), 160 * 1024);
+        const size_t lds = lds_bytes_blk<W, KP>();
+        PFB_REQUIRE(lds <= size_t(160) * 1024, "block scatter needs %zu bytes of LDS", lds);
+        hipLaunchKernelGGL((k_grid_blk<W, KP, BC>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, sval, grid_cur);
+    }
     template <int W, int KP>
     void launch_grid_blk_wk(const GroupArgs &ga, const double2 *sval)
     {
-        allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_blk<W, KP>), 160 * 1024);
-        const size_t lds = lds_bytes_blk<W, KP>();
-        PFB_REQUIRE(lds <= size_t(160) * 1024, "block scatter needs %zu bytes of LDS", lds);
-        hipLaunchKernelGGL((k_grid_blk<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, sval, grid_cur);
+        // (block edge 2: W = 14, 15 on a sort key that carries the 2 x 2-cell blocks -- the 16 x 16-cell frame, see k_grid_blk)
+        if constexpr (W == 14 || W == 15) {
+            if (wd_bc == 2) return launch_grid_blk_wkb<W, KP, 2>(ga, sval);
+        }
+        launch_grid_blk_wkb<W, KP, 4>(ga, sval);
     }
     bool scatter_blk = true;  // register-footprint scatter (k_grid_blk); PFBHIP_SCATTER=walk selects k_grid_mp
     // record-driven register-footprint scatter (k_grid_rec): single-pass plans without ES-kernel w-planes
@@ -730,7 +739,7 @@ struct pfbhip_gridder {
     // one-plane w-scheme (info.wmode == 2, gridder_wd_api.hpp): K kernel functions per axis, their derivative tables, the K
     // complex coefficients of every sorted visibility; d_pval then holds K values per visibility
     WdArgs wd{};
-    int wd_bc = 4;  // block edge of the one-plane scatter's register frame (2: the sort key carries 2 x 2-cell blocks)
+    int wd_bc = 4;  // block edge of the register-footprint scatters' frame (2: the sort key carries 2 x 2-cell blocks; W = 14, 15)
     DevBuf<double> d_dtab;
     DevBuf<double2> d_cw;
     bool wd_small = false;  // few work items: one scatter launch with the atomic tile flush instead of four colour launches
@@ -744,14 +753,22 @@ struct pfbhip_gridder {
     int stamp_mode = 0;  // PFBHIP_STAMP: 1 = record scatter, 2 = row-walk gather
     DevBuf<unsigned long long> d_stamps;  // PFBHIP_STAMP=1: in-kernel phase stamps of the record scatter (8 words per colour work item)
     DevBuf<double2> d_pval;
+    template <int W, int KP, int BC>
+    void launch_grid_rec_wkb(const GroupArgs &ga)
+    {
+        allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_rec<W, KP, BC>), 160 * 1024);
+        const size_t lds = lds_bytes_blk<W, KP>();
+        PFB_REQUIRE(lds <= size_t(160) * 1024, "record scatter needs %zu bytes of LDS", lds);
+        hipLaunchKernelGGL((k_grid_rec<W, KP, BC>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, d_rec.p, d_pval.p,
+                           grid_cur);
+    }
     template <int W, int KP>
     void launch_grid_rec_wk(const GroupArgs &ga)
     {
-        allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_rec<W, KP>), 160 * 1024);
-        const size_t lds = lds_bytes_blk<W, KP>();
-        PFB_REQUIRE(lds <= size_t(160) * 1024, "record scatter needs %zu bytes of LDS", lds);
-        hipLaunchKernelGGL((k_grid_rec<W, KP>), dim3(ga.a.nwork), dim3(blk_threads(kp_max)), lds, stream, ga, d_rec.p, d_pval.p,
-                           grid_cur);
+        if constexpr (W == 14 || W == 15) {
+            if (wd_bc == 2) return launch_grid_rec_wkb<W, KP, 2>(ga);
+        }
+        launch_grid_rec_wkb<W, KP, 4>(ga);
     }
     template <int W>
     void launch_grid_mp_w(int plane0, int kp, const double2 *sval)
@@ -1296,10 +1313,11 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
                 const double plane_cost = own ? own_pt * double(nu) * double(nv)
                                               : 1.2 * (fft2d_seconds(nu, nv) + 3.0 * 16.0 * double(nu) * double(nv) / 5.0e12);
                 double gridcost = nvis * double(nder > 0 ? touched : std::min<int64_t>(touched, npl)) * 0.30e-9;
-                // (one-plane scatter: a lane holds ceil((W + 3) / 3) rows of the block frame and reads that many kernel entries
-                // per visibility from LDS -- 7 at W = 16, 6 at W = 13..15: measured at C2, W = 15 against 16: grid 2.27 against
-                // 2.38 ms, the gather indifferent)
-                if (nder > 0) gridcost *= 0.82 + 0.03 * double((r.W + 3 + 2) / 3);
+                // (one-plane scatter: the cells a lane holds of the block frame -- 7 rows of 3 x 20 lanes at W = 16, 4 rows of 4 x 16 lanes
+                // up to W = 15 (2 x 2-cell anchoring at 14 / 15, the sort's 4 x 4 blocks below: fewer flushes) -- and the gather's W
+                // steps: measured at C2, grid + degrid W = 16: 2.38 + 1.66 ms, W = 15: 1.88 + 1.63, relative to the 3.9 ms the
+                // constant above was last checked against)
+                if (nder > 0) gridcost *= r.W >= 16 ? 1.03 : (r.W >= 14 ? 0.90 : 0.87);
                 const double cost = double(npl) * plane_cost + gridcost;
                 // cheapest wins; within 1 % the more accurate row does (W is free up to 16, so the best row
                 // that maps to the same grid and plane count usually beats the requested epsilon)
@@ -1509,11 +1527,12 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     const std::string smode = senv != nullptr ? std::string(senv) : std::string("auto");
     g->scatter_blk = smode != "walk";
     m.key_sub = (g->scatter_blk && nkeys * 64 < (int64_t(1) << 32) - 2) ? 64 : 1;
-    // one-plane scatter at W = 14 / 15: a 16 x 16-cell register frame anchored on 2 x 2-cell blocks (gridder_kernels_wd.hpp);
-    // PFBHIP_WD_BLOCK=4 keeps the 4 x 4 anchoring (18 x 18 frame on 3 x 20 lanes)
+    // register-footprint scatters at W = 14 / 15: a 16 x 16-cell register frame anchored on 2 x 2-cell blocks (k_grid_blk,
+    // k_grid_rec, k_grid_wd); PFBHIP_WD_BLOCK=4 keeps the 4 x 4 anchoring (17 / 18-cell frame on 3 x 20 lanes).  ES-plane plans whose
+    // (tile, plane, block) key would not fit 32 bits (C5: 409 600 tiles x 64 planes) stay on 4 x 4 blocks.
     {
         const char *benv = std::getenv("PFBHIP_WD_BLOCK");
-        const bool want2 = info.wmode == 2 && (info.W == 14 || info.W == 15) && !(benv != nullptr && benv[0] == '4');
+        const bool want2 = (info.W == 14 || info.W == 15) && !(benv != nullptr && benv[0] == '4');
         if (m.key_sub == 64 && want2 && nkeys * 256 < (int64_t(1) << 32) - 2) m.key_sub = 256;
     }
     g->wd_bc = wd_block_edge(int(info.W), m.key_sub == 256);

@@ -303,18 +303,32 @@ __device__ __forceinline__ void blk_tile_to_grid(const GroupArgs &ga, const Work
     }
 }
 
-template <int W, int KP>
+// Block edge BC and lane layout of the register frame (round 4b, all three register-footprint scatters): the frame is FP = W + BC - 1
+// cells a side.  FP <= 16: 16 columns x 4 row groups (rows 4 k + g), ceil(FP / 4) <= 4 cells per lane and every lane at work -- W <= 13
+// with the 4 x 4-cell blocks of the tile sort, W = 14 / 15 with 2 x 2-cell blocks when the sort key carries them (key_sub = 256).
+// FP > 16 (W = 16; W = 14 / 15 on a coarse key): 20 columns x 3 row groups (rows 3 k + g), up to 7 cells per lane.
+__host__ __device__ constexpr bool blk_frame16(int W, int BC) { return W + BC - 1 <= 16; }
+__host__ __device__ constexpr int blk_frame_rows(int W, int BC)
+{
+    return blk_frame16(W, BC) ? (W + BC - 1 + 3) / 4 : (W + BC - 1 + 2) / 3;
+}
+__host__ __device__ constexpr int blk_edge(int W, bool fine_key) { return (W == 14 || W == 15) && fine_key ? 2 : BLK_CELLS; }
+
+template <int W, int KP, int BC>
 __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, const double2 *__restrict__ sval,
                                                            double2 *__restrict__ grid)
 {
     const PlaneArgs &a = ga.a;
     constexpr int D = kernel_poly_degree_c(W);
-    constexpr int L = TILE + W - 1;
     constexpr int LS = blk_stride(W, KP);
     constexpr int LL = blk_tile_rows(W) * LS;
-    constexpr int FP = W + BLK_CELLS - 1;  // footprint edge of a block
-    constexpr int NR = blk_rows_per_lane(W);
-    constexpr int G = BLK_CELLS - 1;       // zero guard in front of the kernel values
+    constexpr int FP = W + BC - 1;  // footprint edge of a block
+    constexpr bool F16 = blk_frame16(W, BC);
+    constexpr int NCOL = F16 ? 16 : 20, NGRP = F16 ? 4 : 3, SH = BC == 4 ? 2 : 1;
+    constexpr int NR = blk_frame_rows(W, BC);
+    constexpr int G = BC - 1;       // zero guard in front of the kernel values
+    static_assert(BC == 2 || BC == 4, "block edge: 2 or 4 cells");
+    static_assert(FP <= NCOL && NR * NGRP >= FP && NGRP * (NR - 1) + NGRP - 1 + G < 24, "frame does not fit the lane layout / scratch line");
     const int BLK_THREADS = int(blockDim.x);  // blk_threads(planes per pass of the plan) <= blk_threads(KP)
     extern __shared__ double lds[];
     double *wtab = lds + 2 * KP * LL;  // own layout: the tiles of this launch's KP planes, then the tables
@@ -354,9 +368,9 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
     double c[D + 1];
 #pragma unroll
     for (int k = 0; k <= D; ++k) c[k] = (b < W && lane < 32) ? a.ktab[b * (D + 1) + k] : 0.0;
-    // cell ownership: lane = 20 g + cc, rows 3 k + g
-    const int g = lane / 20, cc = lane - 20 * g;
-    const bool act = g < 3 && cc < FP;
+    // cell ownership: lane = NCOL g + cc, rows NGRP k + g
+    const int g = lane / NCOL, cc = lane - NCOL * g;
+    const bool act = g < NGRP && cc < FP;
     // SU[t + G] (lanes 0..15), SV[t + G] at scr + 24 (lanes 16..31); lanes 32..63 write (zeros) to dump slots 48..79
     const int wslot = lane < 16 ? lane + G : (lane < 32 ? lane + 8 + G : lane + 16);
     __syncthreads();
@@ -372,11 +386,11 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
         for (int p = 0; p < KP; ++p) are[k][p] = aim[k][p] = 0.0;
 
     auto flush = [&](int key) {
-        const int r0 = (key >> 8) * BLK_CELLS, c0 = (key & 255) * BLK_CELLS;
+        const int r0 = (key >> 8) * BC, c0 = (key & 255) * BC;
         if (act) {
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
-                const int r = 3 * k + g;
+                const int r = NGRP * k + g;
                 if (r < FP) {
                     const int off = (r0 + r) * LS + c0 + cc;
 #pragma unroll
@@ -444,18 +458,18 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_blk(GroupArgs ga, cons
         for (int i = 0; i < nb; ++i) {
             const int kk = __builtin_amdgcn_readlane(keyv, i);
             const int slu = kk >> 8, slv = kk & 255;
-            const int key = ((slu >> 2) << 8) | (slv >> 2);
+            const int key = ((slu >> SH) << 8) | (slv >> SH);
             if (key != cur) {
                 if (cur >= 0) flush(cur);
                 cur = key;
             }
             const double *sc = scr + (i & 1) * BLK_SCRATCH;
-            const int du = slu & 3, dv = slv & 3;
+            const int du = slu & (BC - 1), dv = slv & (BC - 1);
             const double kvc = sc[24 + cc - dv + G];
             const double *su = sc + (g - du + G);
             double kuv[NR];
 #pragma unroll
-            for (int k = 0; k < NR; ++k) kuv[k] = su[3 * k];
+            for (int k = 0; k < NR; ++k) kuv[k] = su[NGRP * k];
             stage_a((i + 1) & 63);  // unconditional (one basic block); past the batch end it rewrites a line nobody reads
             double vr[KP], vi[KP];
 #pragma unroll
@@ -513,7 +527,7 @@ static_assert(sizeof(VisRec) == 32, "VisRec layout");
 // inside an allocation's slack, a memory fault when a small plan's arrays ended at a page boundary.)
 constexpr int REC_PAD = 136;
 
-template <int W, int KP>
+template <int W, int KP, int BC>
 __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, const VisRec *__restrict__ rec,
                                                                const double2 *__restrict__ pval, double2 *__restrict__ grid)
 {
@@ -521,10 +535,14 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
     constexpr int D = kernel_poly_degree_c(W);
     constexpr int LS = blk_stride(W, KP);
     constexpr int LL = blk_tile_rows(W) * LS;
-    constexpr int FP = W + BLK_CELLS - 1;
-    constexpr int NR = blk_rows_per_lane(W);
-    constexpr int G = BLK_CELLS - 1;
-    constexpr bool SKIP = (FP % 3) == 1;
+    constexpr int FP = W + BC - 1;
+    constexpr bool F16 = blk_frame16(W, BC);   // (frame and lane layout: see k_grid_blk)
+    constexpr int NCOL = F16 ? 16 : 20, NGRP = F16 ? 4 : 3;
+    constexpr int NR = blk_frame_rows(W, BC);
+    constexpr int G = BC - 1;
+    constexpr bool SKIP = !F16 && (FP % 3) == 1;
+    static_assert(BC == 2 || BC == 4, "block edge: 2 or 4 cells");
+    static_assert(FP <= NCOL && NR * NGRP >= FP && NGRP * (NR - 1) + NGRP - 1 + G < 24, "frame does not fit the lane layout / scratch line");
     constexpr int NLINE = 3;  // scratch lines per wave (blk_fixed_doubles reserves 3 * BLK_SCRATCH per wave for this kernel)
     const int BLK_THREADS = int(blockDim.x);
     extern __shared__ double lds[];
@@ -579,11 +597,11 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
     for (int i = threadIdx.x; i < (BLK_THREADS / 64) * NLINE * BLK_SCRATCH; i += BLK_THREADS) scr_all[i] = 0.0;
 
     char *scr = reinterpret_cast<char *>(scr_all + wave * NLINE * BLK_SCRATCH);
-    const int g = lane / 20, cc = lane - 20 * g;
-    const bool act = g < 3 && cc < FP;
+    const int g = lane / NCOL, cc = lane - NCOL * g;
+    const bool act = g < NGRP && cc < FP;
     const int wslot = lane < 16 ? lane + G : (lane < 32 ? lane + 8 + G : lane + 16);
     char *wptr = scr + wslot * 8;      // + line * BLK_SCRATCH * 8: where this lane writes its kernel value
-    const char *suptr = scr + g * 8;   // + offu + 24 k: u-kernel values of the lane's rows
+    const char *suptr = scr + g * 8;   // + offu + 8 NGRP k: u-kernel values of the lane's rows
     const char *svptr = scr + cc * 8;  // + offv: v-kernel value of the lane's column
     __syncthreads();
 
@@ -599,16 +617,16 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
     // footprint -> LDS tile: one address per flush (plane / row offsets are immediates where they fit 16 bits)
     char *const tile0 = reinterpret_cast<char *>(lds) + (g * LS + cc) * 8;
     auto flush = [&](int blk) {
-        const int r0 = (blk >> 8) * BLK_CELLS, c0 = (blk & 255) * BLK_CELLS;
+        const int r0 = (blk >> 8) * BC, c0 = (blk & 255) * BC;
         char *base = tile0 + (r0 * LS + c0) * 8;
         if (act) {
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
-                if (3 * k + g < FP) {
+                if (NGRP * k + g < FP) {
 #pragma unroll
                     for (int p = 0; p < KP; ++p) {
-                        unsafeAtomicAdd(reinterpret_cast<double *>(base + ((2 * p) * LL + 3 * k * LS) * 8), are[k][p]);
-                        unsafeAtomicAdd(reinterpret_cast<double *>(base + ((2 * p + 1) * LL + 3 * k * LS) * 8), aim[k][p]);
+                        unsafeAtomicAdd(reinterpret_cast<double *>(base + ((2 * p) * LL + NGRP * k * LS) * 8), are[k][p]);
+                        unsafeAtomicAdd(reinterpret_cast<double *>(base + ((2 * p + 1) * LL + NGRP * k * LS) * 8), aim[k][p]);
                     }
                 }
             }
@@ -663,7 +681,10 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
         for (int p = 0; p < KP; ++p) asm volatile("" ::"s"(pq[u][p].x), "s"(pq[u][p].y));
     }
     zptr += 3 * 32;  // next kernel argument to request: visibility s + 3
-    if (nmine > 0) cur = kq[0].x;
+    // block of a visibility: the record's 4 x 4 block, or the 2 x 2 block of its first-tap cell (key = (lu << 8) | lv); scratch byte
+    // offsets: the record's (4 x 4 anchoring), or from the cell's position in its 2 x 2 block
+    auto block_of = [](const int4 &r) { return BC == 4 ? r.x : ((r.w >> 1) & 0x0F0F); };
+    if (nmine > 0) cur = block_of(kq[0]);
     for (uint32_t wb = 0; wb < nmine; wb += 63) {  // L2 window: 63 visibilities = 21 trips of the unrolled loop
         asm volatile("" ::"v"(warm));
         warm = touch(j0 + wb + 63);
@@ -678,15 +699,17 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
             zptr += 32;
 
             const int4 rk = kq[u];
-            if (rk.x != cur) {
+            const int bnow = block_of(rk);
+            if (bnow != cur) {
                 flush(cur);
-                cur = rk.x;
+                cur = bnow;
             }
-            const double kvc = *reinterpret_cast<const double *>(svptr + u * (BLK_SCRATCH * 8) + rk.z);
-            const char *su = suptr + u * (BLK_SCRATCH * 8) + rk.y;
+            const int offu = BC == 4 ? rk.y : 8 * (G - ((rk.w >> 8) & 1)), offv = BC == 4 ? rk.z : 8 * (24 + G - (rk.w & 1));
+            const double kvc = *reinterpret_cast<const double *>(svptr + u * (BLK_SCRATCH * 8) + offv);
+            const char *su = suptr + u * (BLK_SCRATCH * 8) + offu;
             double kuv[NR];
 #pragma unroll
-            for (int k = 0; k < NR; ++k) kuv[k] = *reinterpret_cast<const double *>(su + 24 * k);
+            for (int k = 0; k < NR; ++k) kuv[k] = *reinterpret_cast<const double *>(su + 8 * NGRP * k);
             *reinterpret_cast<double *>(wptr + nx * (BLK_SCRATCH * 8)) = kernel_value(znext);  // stage A(s + 1)
             // The scalar requests for visibility s + 2 go out behind the wait for the scratch reads (the empty asm reads
             // their destinations and is a compiler barrier for memory operations).  Issued here they have the FMAs below
@@ -720,7 +743,7 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
             }
             // "use" the record's spare fourth word when its set is current: otherwise its register is handed out again while
             // the load that writes it is in flight, and that write waits for the load (an lgkmcnt(0) right behind the requests)
-            asm volatile("" ::"s"(rk.w));
+            asm volatile("" ::"s"(rk.x), "s"(rk.y), "s"(rk.z), "s"(rk.w));
         }
     }
     }
