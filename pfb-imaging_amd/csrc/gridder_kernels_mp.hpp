@@ -572,12 +572,16 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
     const uint32_t pbytes = uint32_t(ga.kp_alloc) * 16u;  // bytes of values per visibility
     const char *rbase = reinterpret_cast<const char *>(rec);
     const char *pbase = reinterpret_cast<const char *>(pval);
-    // per-lane kernel-argument pointer (zu for lanes 0..15, zv for 16..31), coefficients requested before the tile is cleared
-    const char *zptr = rbase + size_t(j0) * 32 + (lane < 16 ? 0 : 8);
+    // Kernel values are evaluated for TWO visibilities at a time (round 4b): lanes 0..15 zu / 16..31 zv of the pair's first
+    // visibility, 32..47 zu / 48..63 zv of its second -- one Horner round per pair with every lane at work (one visibility at a time
+    // left lanes 32..63 idle).  Per-lane kernel-argument pointer: visibility j0 + vsel, + 2 per pair; coefficients requested before
+    // the tile is cleared.
+    const int axis = (lane >> 4) & 1, vsel = lane >> 5;
+    const char *zptr = rbase + (size_t(j0) + size_t(vsel)) * 32 + (axis ? 8 : 0);
     const int b = lane & 15;
     double c[D + 1];
 #pragma unroll
-    for (int k = 0; k <= D; ++k) c[k] = (b < W && lane < 32) ? a.ktab[b * (D + 1) + k] : 0.0;
+    for (int k = 0; k <= D; ++k) c[k] = b < W ? a.ktab[b * (D + 1) + k] : 0.0;
     // Warm the L2 with the records / values of 64 visibilities (one per lane) ahead of the walk, whose own requests --
     // two visibilities ahead -- then never wait for HBM.  The loaded words are consumed (an empty asm) at the next refresh.
     static_assert(REC_PAD >= 63 + 63 + 3, "the warm-up reads one entry per lane up to 63 + 63 past the current visibility");
@@ -588,9 +592,10 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
         return double(t0) + t1;
     };
     double warm = touch(j0);
-    double zq[3];
+    double zq[3];  // z of the lane's axis for the next three PAIRS (slot = pair index mod 3)
 #pragma unroll
-    for (int u = 0; u < 3; ++u) zq[u] = *reinterpret_cast<const double *>(zptr + u * 32);
+    for (int u = 0; u < 3; ++u) zq[u] = *reinterpret_cast<const double *>(zptr + u * 64);
+    zptr += 3 * 64;
 
     for (int i = threadIdx.x; i < 2 * KP * LL; i += BLK_THREADS) lds[i] = 0.0;
     for (int i = threadIdx.x; i < W * (D + 1); i += BLK_THREADS) wtab[i] = a.ktab[i];
@@ -599,8 +604,13 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
     char *scr = reinterpret_cast<char *>(scr_all + wave * NLINE * BLK_SCRATCH);
     const int g = lane / NCOL, cc = lane - NCOL * g;
     const bool act = g < NGRP && cc < FP;
-    const int wslot = lane < 16 ? lane + G : (lane < 32 ? lane + 8 + G : lane + 16);
-    char *wptr = scr + wslot * 8;      // + line * BLK_SCRATCH * 8: where this lane writes its kernel value
+    // where this lane writes its kernel value: slot b + G of SU (u lanes) / SV at + 24 (v lanes) of the line of ITS visibility.
+    // Visibility s lives in line s mod 3; the pair (s + 1, s + 2) is evaluated while visibility s (odd within a block of six) is
+    // processed, into the two lines that are not being read: wq[q] for s = 2 q + 1.
+    char *const went = scr + ((axis ? 24 : 0) + b + G) * 8;
+    char *wq[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) wq[q] = went + ((2 * q + 2 + vsel) % 3) * (BLK_SCRATCH * 8);
     const char *suptr = scr + g * 8;   // + offu + 8 NGRP k: u-kernel values of the lane's rows
     const char *svptr = scr + cc * 8;  // + offv: v-kernel value of the lane's column
     __syncthreads();
@@ -651,7 +661,11 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
     };
     static_assert((D & 1) == 0, "kernel_value assumes an even polynomial degree");
     const unsigned long long ts1 = stamp ? __builtin_readcyclecounter() : 0ull;
-    if (nmine > 0) *reinterpret_cast<double *>(wptr) = kernel_value(zq[0]);  // stage A(0) -> line 0
+    if (nmine > 0) {  // pair 0 -> lines 0, 1
+        *reinterpret_cast<double *>(wq[2]) = kernel_value(zq[0]);
+        zq[0] = *reinterpret_cast<const double *>(zptr);
+        zptr += 64;
+    }
     int cur = -1;
     int4 kq[3];
     double2 pq[3][KP];
@@ -680,23 +694,19 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
 #pragma unroll
         for (int p = 0; p < KP; ++p) asm volatile("" ::"s"(pq[u][p].x), "s"(pq[u][p].y));
     }
-    zptr += 3 * 32;  // next kernel argument to request: visibility s + 3
     // block of a visibility: the record's 4 x 4 block, or the 2 x 2 block of its first-tap cell (key = (lu << 8) | lv); scratch byte
     // offsets: the record's (4 x 4 anchoring), or from the cell's position in its 2 x 2 block
     auto block_of = [](const int4 &r) { return BC == 4 ? r.x : ((r.w >> 1) & 0x0F0F); };
     if (nmine > 0) cur = block_of(kq[0]);
-    for (uint32_t wb = 0; wb < nmine; wb += 63) {  // L2 window: 63 visibilities = 21 trips of the unrolled loop
+    for (uint32_t wb = 0; wb < nmine; wb += 60) {  // L2 window: 60 visibilities = 10 trips of the unrolled loop
         asm volatile("" ::"v"(warm));
-        warm = touch(j0 + wb + 63);
-        const uint32_t wend = min(wb + 63u, nmine);
-    for (uint32_t sb = wb; sb < wend; sb += 3) {
+        warm = touch(j0 + wb + 60);
+        const uint32_t wend = min(wb + 60u, nmine);
+    for (uint32_t sb = wb; sb < wend; sb += 6) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            if (sb + uint32_t(u) >= wend) break;
-            const int ld = (u + 2) % 3, nx = (u + 1) % 3;
-            const double znext = zq[nx];                        // z(s + 1)
-            zq[u] = *reinterpret_cast<const double *>(zptr);  // z(s + 3); z(s) was consumed one iteration ago
-            zptr += 32;
+        for (int i6 = 0; i6 < 6; ++i6) {
+            if (sb + uint32_t(i6) >= wend) break;
+            const int u = i6 % 3, ld = (u + 2) % 3;
 
             const int4 rk = kq[u];
             const int bnow = block_of(rk);
@@ -710,7 +720,12 @@ __global__ void __launch_bounds__(blk_threads(KP)) k_grid_rec(GroupArgs ga, cons
             double kuv[NR];
 #pragma unroll
             for (int k = 0; k < NR; ++k) kuv[k] = *reinterpret_cast<const double *>(su + 8 * NGRP * k);
-            *reinterpret_cast<double *>(wptr + nx * (BLK_SCRATCH * 8)) = kernel_value(znext);  // stage A(s + 1)
+            if (i6 & 1) {  // kernel values of the pair (s + 1, s + 2) -> their lines
+                const int q = i6 >> 1, slot = (q + 1) % 3;
+                *reinterpret_cast<double *>(wq[q]) = kernel_value(zq[slot]);
+                zq[slot] = *reinterpret_cast<const double *>(zptr);  // z of the pair three pairs on
+                zptr += 64;
+            }
             // The scalar requests for visibility s + 2 go out behind the wait for the scratch reads (the empty asm reads
             // their destinations and is a compiler barrier for memory operations).  Issued here they have the FMAs below
             // and the next iteration's kernel evaluation to arrive in.
