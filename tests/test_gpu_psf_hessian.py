@@ -134,6 +134,38 @@ def test_hesspsf_dot_idot():
     with pytest.raises(ValueError):
         h.dot(np.zeros((1, 2, 32, 32)))
 
+def test_precond_hesspsf_cube():
+    """The cube-level HessPSF of operators/precond.py (precond.py:12-154): beam required, eta per value / band / pixel, dot aliases
+    self.xout, idot is a plain CG from x0 (no direct-estimate start) and inverts dot to CG tolerance."""
+    from pfb_imaging_amd.operators import Preconditioner, require_protocol
+    from pfb_imaging_amd.operators.precond import HessPSF
+
+    psf, psfhat, abspsf, x, beam = _psf_case(nband=2, nx=32, ny=32, nxp=64, nyp=64, seed=5)
+    abspsf = 1.0 + 0.2 * abspsf / abspsf.max()
+    with pytest.raises(ValueError):
+        HessPSF(32, 32, abspsf, beam=None)
+    with pytest.raises(NotImplementedError):
+        HessPSF(32, 32, abspsf, beam=beam, memory_greedy=False)
+    with pytest.raises(ValueError):
+        HessPSF(32, 32, abspsf, beam=beam, eta=1)
+    for eta in (0.3, np.array([0.1, 0.2]), 0.05 + np.random.default_rng(1).random((2, 32, 32))):
+        h = HessPSF(32, 32, abspsf, beam=beam, eta=eta, cgtol=1e-10, cgmaxit=400, cgverbose=0)
+        require_protocol(h, Preconditioner, "precond")
+        out = h.dot(x)
+        assert out is h.xout
+        e = eta if np.ndim(eta) == 3 else np.broadcast_to(np.reshape(np.atleast_1d(eta) * np.ones(2), (2, 1, 1)), x.shape)
+        ref = fftconv.hess_psf_dot(x, abspsf, 64, beam=beam, eta=0.0) + e * x
+        assert rel(out, ref) < 1e-11 and rel(h.hdot(x), ref) < 1e-11
+        sol = h.idot(ref.copy())
+        assert sol is not h.xout and rel(sol, x) < 1e-6
+        # a start vector is honoured (and not required)
+        assert rel(h.idot(ref.copy(), x0=0.9 * x), x) < 1e-6
+    h1 = HessPSF(32, 32, abspsf[:1], beam=beam[:1], eta=0.5)
+    assert rel(h1.dot(x[0])[0], fftconv.hess_psf_dot(x[:1], abspsf[:1], 64, beam[:1], 0.5)[0]) < 1e-11
+    with pytest.raises(ValueError):
+        h1.dot(np.zeros((1, 1, 32, 32)))
+
+
 
 def test_pcg_psf_per_band_solves():
     """opt.pcg_psf (opt/pcg.py:317-441): per-band CG on beam (PSF (*) (beam x)) + eta x == the numpy restatement's solve."""
