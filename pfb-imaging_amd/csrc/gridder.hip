@@ -1051,6 +1051,17 @@ struct pfbhip_gridder {
     // x -> sacc, folding the x * corr * beam step into the fused pad kernel where possible
     void prepare_and_degrid(const double *x, const double *beam, double2 *sacc)
     {
+        // The side-stream clear of the scatter's planes starts with the apply, under the degridding side's row transforms (round
+        // 4b; PFBHIP_CLEAR_EARLY=0: in front of the gather, as before).  The gather's workgroups fill every CU's registers (three
+        // waves of 168 VGPRs per SIMD), so a clear issued next to it only got onto the chip as the gather drained and ran into
+        // the scatter; the fused row-FFT kernels leave room.  C2: degrid 1.647 -> 1.594 ms, pad_fft + 0.01, apply 5.91 -> 5.86 ms.
+        static const bool clear_early = [] {
+            const char *e = std::getenv("PFBHIP_CLEAR_EARLY");
+            return !(e != nullptr && e[0] == '0');
+        }();
+        // (one plane only: with the three planes of the polynomial scheme the clear's 0.9 GB cost pad_fft what they save the gather,
+        // 9.73 against 9.77 ms)
+        if (clear_early && side_clear_pending && info.nplanes == 1) side_clear();
         if (fused && info.nactive != 0 && info.nwork != 0 && fused_pad_takes_prep(rowfft_u, fgeom)) {
             FusedPrep p;
             p.x = x;
