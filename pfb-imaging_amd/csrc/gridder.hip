@@ -1699,8 +1699,12 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     // it, ONLY with PFBHIP_SCATTER=rec_es.  Measured (gpurun_out/r03w, r03x): 8192^2 image, 19 planes, 9.5e6 visibilities: scatter
     // 21.2 -> 17.8 ms, + 1.4 ms of plane values (88 bytes per visibility and pass), apply 73.2 -> 70.9 ms; C5: 195 -> 190 ms,
     // + 13 ms of plane values, apply 1035 -> 1044 ms -- there the scatter waits on the records / values of 1e8 visibilities
-    // (6 GB per pass set) whichever kernel runs.  No rule that separates the two cases was found; k_grid_blk stays the default.
-    const bool rec_es = prm.do_wgridding && info.wmode == 0 && info.nactive > 0 && !work.empty() && smode == "rec_es";
+    // (6 GB per pass set) whichever kernel runs.  Round 4b: with the 16 x 16-cell frame (W <= 13, or W = 14 / 15 on the finer sort key) and
+    // its paired kernel evaluation the record form is 16 % ahead of k_grid_blk at 8192^2 / 19 planes (17.2 + 1.5 against 20.4 ms, apply
+    // 69.9 against 72.2); at C5 (4 x 4 blocks: the key does not fit) it is 6.5 % ahead and the plane values eat that (1038.6 against
+    // 1033.3 ms).  Default: the record form where the 16 x 16 frame applies and the plan is not C5's size; k_grid_blk otherwise.
+    const bool rec_es_auto = smode == "auto" && blk_frame16(int(info.W), g->wd_bc) && info.nactive <= int64_t(30000000);
+    const bool rec_es = prm.do_wgridding && info.wmode == 0 && info.nactive > 0 && !work.empty() && (smode == "rec_es" || rec_es_auto);
     g->scatter_rec = (rec_mode || rec_es) && g->scatter_blk && smode != "block";
     g->pval_from_gather = rec_mode && g->scatter_rec;
     {
