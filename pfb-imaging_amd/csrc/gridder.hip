@@ -1329,6 +1329,10 @@ static void choose_kernel(pfbhip_gridder *g, double wlo, double whi, double tmax
                 // steps: measured at C2, grid + degrid W = 16: 2.38 + 1.66 ms, W = 15: 1.88 + 1.63, relative to the 3.9 ms the
                 // constant above was last checked against)
                 if (nder > 0) gridcost *= r.W >= 16 ? 1.03 : (r.W >= 14 ? 0.90 : 0.87);
+                // (the multi-plane register-footprint scatters hold the same frames: 4 cells per lane up to W = 15 against 7 at W = 16 --
+                // k_grid_rec at C2 on three polynomial planes, W = 16: grid 2.31 of 4.05 ms of scatter + gather; the gathers walk 16
+                // steps whatever W)
+                else if (wgrid) gridcost *= r.W >= 16 ? 1.0 : 0.92;
                 const double cost = double(npl) * plane_cost + gridcost;
                 // cheapest wins; within 1 % the more accurate row does (W is free up to 16, so the best row
                 // that maps to the same grid and plane count usually beats the requested epsilon)
