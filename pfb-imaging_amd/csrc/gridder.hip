@@ -1708,7 +1708,12 @@ static void create_impl(pfbhip_gridder *g, const double *uvw, const double *freq
     // 69.9 against 72.2); at C5 (4 x 4 blocks: the key does not fit) it is 6.5 % ahead and the plane values eat that (1038.6 against
     // 1033.3 ms).  Default: the record form where the 16 x 16 frame applies and the plan is not C5's size; k_grid_blk otherwise.
     const bool rec_es_auto = smode == "auto" && blk_frame16(int(info.W), g->wd_bc) && info.nactive <= int64_t(30000000);
-    const bool rec_es = prm.do_wgridding && info.wmode == 0 && info.nactive > 0 && !work.empty() && (smode == "rec_es" || rec_es_auto);
+    // (polynomial planes in several passes -- 5 to 10 planes, moderate omega -- can take the same route, k_plane_values in front of each
+    // pass's scatter, on request only: 4096^2 / 10 planes, grid 3.70 + 0.37 ms of plane values against 4.20 for k_grid_blk, apply 13.05
+    // against 13.02 ms -- every visibility is in every pass there, so the values pass costs what the kernel gains)
+    const bool multi_poly = info.wmode == 1 && info.nplanes > g->kp_max;
+    const bool rec_es = prm.do_wgridding && info.nactive > 0 && !work.empty() &&
+                        ((info.wmode == 0 && (smode == "rec_es" || rec_es_auto)) || (multi_poly && smode == "rec_es"));
     g->scatter_rec = (rec_mode || rec_es) && g->scatter_blk && smode != "block";
     g->pval_from_gather = rec_mode && g->scatter_rec;
     {

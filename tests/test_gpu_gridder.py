@@ -305,7 +305,7 @@ def test_scatter_forms_agree(eps, widen, zscale, monkeypatch):
         # w-planes; "rec_es" extends it to ES-kernel plane stacks (their values written per pass by k_plane_values_es: an
         # option, not the default); asked for elsewhere, the plan keeps k_grid_blk
         single_pass = g.info["wmode"] == 1 and g.info["nplanes"] <= 4
-        es = g.info["wmode"] == 0
+        es = g.info["wmode"] == 0 or (g.info["wmode"] == 1 and g.info["nplanes"] > 4)  # (every multi-pass plan)
         assert g.info["scatter_mode"] == {"block": 1, "walk": 0, "rec": 2 if single_pass else 1,
                                           "rec_es": 2 if (single_pass or es) else 1}[mode], g.info
         g.set_weights(c["wgt"])
@@ -330,7 +330,7 @@ def test_scatter_forms_agree(eps, widen, zscale, monkeypatch):
 
 
 @pytest.mark.parametrize("W, sigma", [(13, 1.5), (14, 1.4), (15, 1.3), (16, 1.25)])
-@pytest.mark.parametrize("wmode, widen, zscale", [(0, 30.0, 0.5), (1, 8.0, 0.02)])
+@pytest.mark.parametrize("wmode, widen, zscale", [(0, 30.0, 0.5), (1, 8.0, 0.02), (1, 30.0, 0.1)])
 def test_multi_plane_scatter_frames(W, sigma, wmode, widen, zscale, monkeypatch):
     """The register frames of k_grid_blk / k_grid_rec (csrc/gridder_kernels_mp.hpp; round 4b): 16 x 16 cells on 4 x 16 lanes for
     W <= 15 (2 x 2-cell anchoring and the finer sort key at W = 14, 15), 3 x 20 lanes for W = 16 and under PFBHIP_WD_BLOCK=4 -- ES-kernel
@@ -345,6 +345,7 @@ def test_multi_plane_scatter_frames(W, sigma, wmode, widen, zscale, monkeypatch)
             monkeypatch.setenv("PFBHIP_WD_BLOCK", blk)
             g, kw, mask = gpu_plan(c, epsilon=1e-7, force_wmode=wmode, force=(sigma, W))
             assert g.info["wmode"] == wmode and g.info["W"] == W, g.info
+            assert (g.info["nplanes"] > 4) == (wmode == 0 or widen > 10), g.info  # (the third case: polynomial planes in several passes)
             assert g.info["scatter_block"] == (2 if (blk == "2" and W in (14, 15)) else 4), g.info
             o = oracle_plan(c, g, kw, mask)
             d = g.vis2dirty(c["vis"], c["wgt"])
