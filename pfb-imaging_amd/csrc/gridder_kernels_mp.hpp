@@ -842,10 +842,11 @@ __device__ __forceinline__ void rw_steps(const char *base, const char *base2, do
         rw_steps<KP, D, I + 1>(base, base2, ku, sr, si, buf);
     }
 }
-template <int KP, int I>
+// (NS = W steps: the rows past the support carry zero kernel values)
+template <int NS, int KP, int I>
 __device__ __forceinline__ void rw_steps0(const char *base, const char *base2, double ku, double (&sr)[KP], double (&si)[KP])
 {
-    if constexpr (I < 16) {
+    if constexpr (I < NS) {
         double2 cell[KP];
         rw_load_row<KP, I>(base, base2, cell);
 #pragma unroll
@@ -853,7 +854,7 @@ __device__ __forceinline__ void rw_steps0(const char *base, const char *base2, d
             fmac_row_bcast<I>(sr[k], ku, cell[k].x);
             fmac_row_bcast<I>(si[k], ku, cell[k].y);
         }
-        rw_steps0<KP, I + 1>(base, base2, ku, sr, si);
+        rw_steps0<NS, KP, I + 1>(base, base2, ku, sr, si);
     }
 }
 template <int KP, int D, int I>
@@ -988,7 +989,7 @@ __global__ void __launch_bounds__(MP_THREADS) k_degrid_rw(GroupArgs ga, const Vi
             for (int k = 0; k < KP; ++k) sr[k] = si[k] = 0.0;
             asm volatile("s_nop 1" : "+v"(ku));  // VALU write -> DPP read of the same register needs 2 wait states
             if constexpr (PD == 0) {
-                rw_steps0<KP, 0>(base, base2, ku, sr, si);
+                rw_steps0<W, KP, 0>(base, base2, ku, sr, si);
             } else {
                 double2 cells[PD + 1][KP];
                 rw_prologue<KP, PD, 0>(base, base2, cells);
